@@ -1,0 +1,10 @@
+"""MI355X-native DDSP synthesis hot path (harmonic oscillator bank + filtered noise).
+
+Drop-in for `model/ddsp/harmonic_oscillator.py` and `model/ddsp/filtered_noise.py`
+of kureta/ddsp-pytorch: same constructors, `forward()` / `live()` signatures,
+control-dict keys and state-dict keys, with the compute in hand-written HIP
+kernels (gfx950) behind the C-ABI declared in `include/ddsp_hip.h`.
+"""
+from . import synthetic  # noqa: F401
+
+__all__ = ["synthetic"]

@@ -1,0 +1,95 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes/NumPy front end of oracle/libddsp_oracle.so.
+
+The C file restates model/ddsp/harmonic_oscillator.py:24-75 and
+model/ddsp/filtered_noise.py:7-53 of the reference;
+parity is PINNED by tests/test_oracle_golden.py against tests/golden/*.npz.
+Nothing under ddsp-pytorch_amd/ may import this module.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_DIR, "libddsp_oracle.so")
+_lib = None
+
+_fp = ctypes.POINTER(ctypes.c_float)
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_DIR, "ddsp_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _DIR, "-B", "libddsp_oracle.so"], check=True, capture_output=True)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.ddsp_oracle_osc.restype = ctypes.c_int
+        _lib.ddsp_oracle_osc.argtypes = [_fp] * 8 + [ctypes.c_int] * 5
+        _lib.ddsp_oracle_osc_frames.restype = ctypes.c_int
+        _lib.ddsp_oracle_osc_frames.argtypes = [_fp] * 4 + [ctypes.c_int] * 4
+        _lib.ddsp_oracle_noise.restype = ctypes.c_int
+        _lib.ddsp_oracle_noise.argtypes = [_fp] * 4 + [ctypes.c_int] * 4
+        _lib.ddsp_oracle_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _f32(x):
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def _p(x):
+    return x.ctypes.data_as(_fp) if x is not None else None
+
+
+def threads() -> int:
+    return int(lib().ddsp_oracle_threads())
+
+
+def osc_forward(f0, c, a, hop: int, sample_rate: int, debug: bool = False, live_phase=None):
+    """OscillatorBank.forward (or .live when live_phase [H] is given; it is updated in place).
+
+    f0 [B,T,1], c [B,T,H], a [B,T,1] -> y [B,T*hop]; with debug=True also inc, cum, phi [B,N,H]."""
+    f0, c, a = _f32(f0), _f32(c), _f32(a)
+    B, T, H = c.shape
+    assert f0.shape == (B, T, 1) and a.shape == (B, T, 1)
+    N = T * hop
+    y = np.empty((B, N), np.float32)
+    dbg = [np.empty((B, N, H), np.float32) for _ in range(3)] if debug else [None] * 3
+    if live_phase is not None:
+        assert live_phase.dtype == np.float32 and live_phase.shape == (H,) and live_phase.flags.c_contiguous
+    rc = lib().ddsp_oracle_osc(_p(f0), _p(c), _p(a), _p(y), _p(dbg[0]), _p(dbg[1]), _p(dbg[2]),
+                               _p(live_phase), B, T, H, hop, sample_rate)
+    assert rc == 0
+    if debug:
+        return y, dict(inc=dbg[0], cum=dbg[1], phi=dbg[2])
+    return y
+
+
+def osc_frames(f0, c, sample_rate: int):
+    """Frame-rate increments w [B,T,H] (rad/sample) and normalised amplitudes [B,T,H]."""
+    f0, c = _f32(f0), _f32(c)
+    B, T, H = c.shape
+    w = np.empty((B, T, H), np.float32)
+    amp = np.empty((B, T, H), np.float32)
+    assert lib().ddsp_oracle_osc_frames(_p(f0), _p(c), _p(w), _p(amp), B, T, H, sample_rate) == 0
+    return w, amp
+
+
+def noise_forward(Hm, uniform, hop: int, debug: bool = False):
+    """FilteredNoise.forward with the torch.rand draw `uniform` [B,T,hop] injected. -> y [B,T*hop]."""
+    Hm, uniform = _f32(Hm), _f32(uniform)
+    B, T, F = Hm.shape
+    assert uniform.shape == (B, T, hop)
+    y = np.empty((B, T * hop), np.float32)
+    ir = np.empty((B, T, hop), np.float32) if debug else None
+    assert lib().ddsp_oracle_noise(_p(Hm), _p(uniform), _p(y), _p(ir), B, T, F, hop) == 0
+    return (y, ir) if debug else y

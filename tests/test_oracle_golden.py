@@ -1,0 +1,77 @@
+"""Pins the CPU oracle (oracle/ddsp_oracle.c) against fixtures captured from the reference.
+
+Tolerances: inc / cum / phi bit-exact; y <= 1e-6; noise <= 2e-6.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+from oracle import oracle
+
+OSC_INTERMEDIATE = ["g1_osc_tiny", "g5b_osc_nyquist_finite", "g6_osc_hop100", "g6_osc_hop441", "g6_osc_hop3",
+                    "g6_osc_hop7", "g6_osc_hop160", "g6_osc_hop480", "g6_osc_single_frame"]
+
+
+def bits(x):
+    return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("name", OSC_INTERMEDIATE)
+def test_osc_phase_path_bit_exact(name):
+    g = load_golden(name)
+    y, d = oracle.osc_forward(g["f0"], g["c"], g["a"], int(g["hop"]), int(g["sample_rate"]), debug=True)
+    assert np.array_equal(bits(d["inc"]), bits(g["inc"])), "upsampled increments differ"
+    assert np.array_equal(bits(d["cum"]), bits(g["cum"])), "fl32(double cumsum) differs"
+    assert np.array_equal(bits(d["phi"]), bits(g["phi"])), "phases differ"
+    assert np.max(np.abs(y - g["y"])) <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["g2_osc_cfg2_live", "g3_osc_cfg2_musical", "g4_osc_cfg3_1s"])
+def test_osc_long_clips(name):
+    g = load_golden(name)
+    y, d = oracle.osc_forward(g["f0"], g["c"], g["a"], int(g["hop"]), int(g["sample_rate"]), debug=True)
+    assert np.array_equal(bits(d["phi"][:, g["phi_idx"], :]), bits(g["phi_sub"]))
+    assert np.max(np.abs(y - g["y"])) <= 1e-6
+
+
+def test_osc_cfg1():
+    g = load_golden("g2b_osc_cfg1")
+    y = oracle.osc_forward(g["f0"], g["c"], g["a"], int(g["hop"]), int(g["sample_rate"]))
+    assert np.max(np.abs(y - g["y"])) <= 1e-6
+
+
+def test_osc_frames_g1():
+    g = load_golden("g1_osc_tiny")
+    w, amp = oracle.osc_frames(g["f0"], g["c"], int(g["sample_rate"]))
+    np.testing.assert_allclose(amp, g["amp_frame"], rtol=4e-7, atol=0)
+
+
+def test_osc_nyquist_nan_frame():
+    g = load_golden("g5_osc_nyquist")
+    y, d = oracle.osc_forward(g["f0"], g["c"], g["a"], int(g["hop"]), int(g["sample_rate"]), debug=True)
+    assert np.array_equal(bits(d["phi"]), bits(g["phi"]))
+    assert np.array_equal(np.isnan(y), np.isnan(g["y"])) and np.isnan(y).any()
+    ok = ~np.isnan(y)
+    assert np.max(np.abs(y[ok] - g["y"][ok])) <= 1e-6
+
+
+@pytest.mark.parametrize("name,calls", [("g7_osc_live", 3), ("g7b_osc_live_batch2", 2)])
+def test_osc_live_state(name, calls):
+    g = load_golden(name)
+    state = np.zeros(g["c_0"].shape[-1], np.float32)     # int64 zeros in the reference before call 1
+    for k in range(calls):
+        y = oracle.osc_forward(g[f"f0_{k}"], g[f"c_{k}"], g[f"a_{k}"], int(g["hop"]), int(g["sample_rate"]),
+                               live_phase=state)
+        assert np.array_equal(bits(state), bits(g[f"last_phases_{k}"]))
+        assert np.max(np.abs(y - g[f"y_{k}"])) <= 1e-6
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "g8_noise_*.npz"))))
+def test_noise(path):
+    g = load_golden(os.path.basename(path)[:-4])
+    y, ir = oracle.noise_forward(g["H"], g["uniform"], int(g["hop"]), debug=True)
+    assert np.max(np.abs(ir - g["ir"])) <= 5e-7
+    assert np.max(np.abs(y - g["y"])) <= 2e-6
