@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Benchmark of the DDSP synthesis hot path on MI355X (contract: see the task brief / DESIGN.md §7).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic controls resident in HBM:
+OscillatorBank.forward (4 kernels) + FilteredNoise.forward accumulated into the same buffer
+(`harmonics + noise`, decoder.py:132).  Workload = the configuration BASELINE.json's metric is quoted on:
+batch 512 per GPU, 16 kHz, 100 harmonics, hop 128, 4 s clips, 65 noise bands (cfg4's per-GPU shard;
+weak scaling: every rank synthesises its own 512 rows, no collective on the data path).
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (osc_frame_synth) from HIP events
+recorded on the launch stream during the timed region; `cpu_baseline` times the torch-op restatement of
+the reference's CPU path (oracle/torch_restatement.py) on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import ddsp_pytorch_amd as ddsp  # noqa: E402
+from ddsp_pytorch_amd import synthetic as syn  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_TLANEOPS = 78.6      # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (= 157.3 TFLOP/s fp32 vector / 2)
+
+
+class Conf:
+    def __init__(self, shape):
+        self.n_harmonics, self.sample_rate, self.hop_length = shape.n_harmonics, shape.sample_rate, shape.hop
+
+
+def cpu_baseline(shape, seconds_target=12.0):
+    """Reference CPU path (torch-op restatement) on a bounded sample: B=8 rows of the same workload."""
+    from oracle import torch_restatement as tr
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    b = 8
+    ctl = syn.make_controls(shape, 1004, "all_live", batch=b)
+    f0, c, a, H = (torch.from_numpy(ctl[k]) for k in ("f0", "c", "a", "H"))
+    with torch.no_grad():
+        tr.oscillator_bank(f0, c, a, shape.hop, shape.sample_rate)  # warm-up
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            y = tr.oscillator_bank(f0, c, a, shape.hop, shape.sample_rate)
+            y += tr.filtered_noise(H, shape.hop)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= seconds_target or reps >= 200:
+                break
+    return {"value": b * shape.samples * reps / el, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} passes of batch {b} (of {shape.batch}) x {shape.samples} samples, same shape; torch-op "
+                      f"restatement of harmonic_oscillator.py+filtered_noise.py, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--f0", default="all_live", choices=["all_live", "musical"])
+    ap.add_argument("--batch", type=int, default=0, help="rows per GPU (default: the metric's 512)")
+    ap.add_argument("--tiling", type=int, default=0, help="force harmonics per lane (tuning)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--noise", default="device", choices=["device", "resident"],
+                    help="uniform draw: in-kernel Philox, or a [B,T,hop] tensor already resident in HBM")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    shape = syn.CFG4_PER_GPU
+    if args.batch:
+        shape = syn.SynthShape(shape.name, args.batch, shape.sample_rate, shape.hop, shape.frames, shape.n_harmonics,
+                               shape.n_noise_filters)
+    ctl = syn.make_controls(shape, 1004 + rank, args.f0)
+    x = {k: torch.from_numpy(v).cuda() for k, v in ctl.items()}
+    conf = Conf(shape)
+    osc = ddsp.OscillatorBank(conf).cuda()
+    uniform = torch.rand(shape.batch, shape.frames, shape.hop, device="cuda") if args.noise == "resident" else None
+    if args.tiling:
+        ddsp._lib.check(ddsp._lib.lib().ddsp_osc_set_tiling(args.tiling), "ddsp_osc_set_tiling")
+
+    def step(i):
+        y = osc(x)
+        ddsp.noise_forward(x["H"], shape.hop, uniform=uniform, seed=1234 + rank, offset=i << 32, out=y, accumulate=True)
+        return y
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        y = step(i)
+    ddsp._lib.profile_enable(8 * args.steps + 16)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        y = step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    records = ddsp._lib.profile_read()
+    ddsp._lib.profile_enable(0)
+    assert bool(torch.isfinite(y).all()), "non-finite audio"
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        samples_per_step = world * shape.batch * shape.samples
+        per_kernel = {}
+        for name, ms in records:
+            per_kernel.setdefault(name, []).append(ms)
+        kern_ms = {k: float(np.mean(v)) for k, v in per_kernel.items()}
+        synth_ms = kern_ms.get("osc_frame_synth", float("nan"))
+        # algorithmic bytes of the oscillator per output sample = 4 (y) + 4*(H+2)/hop (c, f0, a)
+        bytes_per_sample = 4.0 + 4.0 * (shape.n_harmonics + 2) / shape.hop
+        launch_samples = shape.batch * shape.samples
+        achieved = launch_samples * bytes_per_sample / (synth_ms * 1e-3) / 1e9
+        hs_per_s = launch_samples * shape.n_harmonics / (synth_ms * 1e-3)
+        line = {
+            "metric": "audio samples/sec/GPU + %HBM-roofline, 16kHz/100-harmonic/batch512",
+            "value": samples_per_step * args.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (phase accumulator f64)", "data": "synthetic",
+            "config": {"workload": f"batch {shape.batch}/GPU x {world} GPU, {shape.sample_rate} Hz, {shape.n_harmonics} harmonics, "
+                                   f"hop {shape.hop}, {shape.frames} frames (4 s), {shape.n_noise_filters} noise bands "
+                                   f"(BASELINE.json configs[3] per-GPU shard; metric's batch512)",
+                       "f0": args.f0, "noise_rng": args.noise, "parallelism": f"batch-sharded x{world}, no collective",
+                       "step": "OscillatorBank.forward + FilteredNoise.forward accumulated (harmonics + noise)"},
+            "samples_per_sec_per_gpu": samples_per_step * args.steps / elapsed / world,
+            "roofline": {"bound": "hbm", "kernel": "osc_frame_synth", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_sample": bytes_per_sample, "avg_launch_ms": synth_ms,
+                         "note": "kernel is VALU-bound (SURVEY §8d): see valu",
+                         "valu": {"harmonic_samples_per_s": hs_per_s, "lane_ops_per_harmonic_sample": 12,
+                                  "achieved_Tlaneops": hs_per_s * 12 / 1e12, "peak_Tlaneops": VALU_PEAK_TLANEOPS,
+                                  "frac": hs_per_s * 12 / 1e12 / VALU_PEAK_TLANEOPS}},
+            "kernel_ms": kern_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(shape)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -3,8 +3,11 @@
 Drop-in for `model/ddsp/harmonic_oscillator.py` and `model/ddsp/filtered_noise.py`
 of kureta/ddsp-pytorch: same constructors, `forward()` / `live()` signatures,
 control-dict keys and state-dict keys, with the compute in hand-written HIP
-kernels (gfx950) behind the C-ABI declared in `include/ddsp_hip.h`.
+kernels (gfx950) behind the C ABI declared in `include/ddsp_hip.h`.
 """
 from . import synthetic  # noqa: F401
+from . import _lib  # noqa: F401
+from .harmonic_oscillator import OscillatorBank, osc_forward  # noqa: F401
+from .filtered_noise import FilteredNoise, noise_forward  # noqa: F401
 
-__all__ = ["synthetic"]
+__all__ = ["OscillatorBank", "FilteredNoise", "osc_forward", "noise_forward", "synthetic"]

@@ -1,0 +1,89 @@
+"""ctypes binding of libddsp_hip.so (C ABI in include/ddsp_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing or a launch
+fails, the caller gets an exception -- never a silent PyTorch/CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_DIR, "libddsp_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+
+
+class DdspHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, jobs: int = 4) -> str:
+    """Compile csrc/*.hip for gfx950 into libddsp_hip.so (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_DIR, "csrc"), f"-j{jobs}"]
+    if force:
+        args.append("-B")
+    r = subprocess.run(args, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise DdspHipError("building libddsp_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return SO_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise DdspHipError(
+            f"{SO_PATH} is missing: the DDSP hot path has no CPU fallback. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C ddsp-pytorch_amd/csrc`.")
+    L = ctypes.CDLL(SO_PATH)
+    vp, i32, u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64
+    L.ddsp_hip_abi_version.restype = i32
+    L.ddsp_hip_abi_version.argtypes = []
+    L.ddsp_osc_scratch_bytes.restype = ctypes.c_size_t
+    L.ddsp_osc_scratch_bytes.argtypes = [i32, i32, i32]
+    L.ddsp_osc_forward.restype = i32
+    L.ddsp_osc_forward.argtypes = [vp] * 8 + [i32] * 5 + [vp]
+    L.ddsp_noise_forward.restype = i32
+    L.ddsp_noise_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, u64, u64, i32, vp]
+    L.ddsp_osc_set_tiling.restype = i32
+    L.ddsp_osc_set_tiling.argtypes = [i32]
+    L.ddsp_profile_enable.restype = i32
+    L.ddsp_profile_enable.argtypes = [i32]
+    L.ddsp_profile_read.restype = i32
+    L.ddsp_profile_read.argtypes = [ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_float), i32]
+    if L.ddsp_hip_abi_version() != ABI_VERSION:
+        raise DdspHipError(f"libddsp_hip.so has ABI {L.ddsp_hip_abi_version()}, expected {ABI_VERSION}: rebuild")
+    _lib = L
+    return L
+
+
+EXPORTS = ("ddsp_hip_abi_version", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_noise_forward",
+           "ddsp_osc_set_tiling", "ddsp_profile_enable", "ddsp_profile_read")
+
+KERNEL_NAMES = {0: "osc_prep", 1: "osc_frame_totals", 2: "osc_scan", 3: "osc_frame_synth", 4: "noise_frame"}
+
+
+def profile_enable(capacity: int) -> None:
+    check(lib().ddsp_profile_enable(capacity), "ddsp_profile_enable")
+
+
+def profile_read(cap: int = 65536):
+    """-> list of (kernel name, milliseconds) recorded since the last read."""
+    ids = (ctypes.c_int * cap)()
+    ms = (ctypes.c_float * cap)()
+    n = lib().ddsp_profile_read(ids, ms, cap)
+    return [(KERNEL_NAMES.get(ids[i], str(ids[i])), float(ms[i])) for i in range(n)]
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc == -1:
+        raise DdspHipError(f"{what}: invalid argument (DDSP_EINVAL)")
+    if rc == -2:
+        raise DdspHipError(f"{what}: shape outside the supported range (DDSP_ERANGE)")
+    raise DdspHipError(f"{what}: HIP error {rc}")

@@ -1,0 +1,70 @@
+// C-ABI odds and ends of libddsp_hip.so (see include/ddsp_hip.h): ABI version, per-kernel event timing.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <vector>
+
+#include "ddsp_hip.h"
+#include "ddsp_internal.h"
+
+extern "C" int ddsp_hip_abi_version(void) { return DDSP_HIP_ABI_VERSION; }
+
+namespace {
+struct Record { hipEvent_t t0, t1; int kernel_id; };
+std::mutex g_mu;
+std::vector<Record> g_pool;  // created by ddsp_profile_enable
+int g_used = 0;
+bool g_on = false;
+}  // namespace
+
+namespace ddsp_prof {
+int begin(int kernel_id, hipStream_t s)
+{
+    if (!g_on) return -1;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_used >= (int)g_pool.size()) return -1;
+    const int slot = g_used++;
+    g_pool[slot].kernel_id = kernel_id;
+    (void)hipEventRecord(g_pool[slot].t0, s);
+    return slot;
+}
+void end(int slot, hipStream_t s)
+{
+    if (slot < 0) return;
+    (void)hipEventRecord(g_pool[slot].t1, s);
+}
+}  // namespace ddsp_prof
+
+extern "C" int ddsp_profile_enable(int capacity)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &r : g_pool) { (void)hipEventDestroy(r.t0); (void)hipEventDestroy(r.t1); }
+    g_pool.clear();
+    g_used = 0;
+    g_on = false;
+    if (capacity <= 0) return 0;
+    g_pool.resize(capacity);
+    for (auto &r : g_pool) {
+        hipError_t e = hipEventCreate(&r.t0);
+        if (e == hipSuccess) e = hipEventCreate(&r.t1);
+        if (e != hipSuccess) { g_pool.clear(); return (int)e; }
+    }
+    g_on = true;
+    return 0;
+}
+
+extern "C" int ddsp_profile_read(int *kernel_ids, float *ms, int cap)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    for (int i = 0; i < g_used && n < cap; ++i) {
+        if (hipEventSynchronize(g_pool[i].t1) != hipSuccess) break;
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, g_pool[i].t0, g_pool[i].t1) != hipSuccess) break;
+        kernel_ids[n] = g_pool[i].kernel_id;
+        ms[n] = t;
+        ++n;
+    }
+    g_used = 0;
+    return n;
+}

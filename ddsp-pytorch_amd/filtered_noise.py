@@ -1,0 +1,63 @@
+"""Drop-in `FilteredNoise` (reference: model/ddsp/filtered_noise.py:35-53) on the HIP kernel.
+
+`forward(x)` reads `x['H'] [B,T,F]` and returns `[B, T*hop]`.  The reference draws its noise with
+`torch.rand(B,T,hop)` on the CPU global generator and copies it to the device (:44-48); that stays
+the default (`rng='host'`, reproducible with torch.manual_seed exactly like the reference).
+`rng='device'` draws inside the kernel (Philox4x32-10; a different stream); `noise=` injects a draw.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def noise_forward(Hmag, hop: int, uniform=None, seed: int = 0, offset: int = 0, out=None, accumulate=False):
+    """Raw launcher over the C ABI (include/ddsp_hip.h: ddsp_noise_forward)."""
+    if Hmag.dim() != 3:
+        raise ValueError("expected H [B,T,F]")
+    if not Hmag.is_cuda:
+        raise _lib.DdspHipError("FilteredNoise runs on the GPU only (no CPU fallback): move the controls to cuda")
+    Hmag = Hmag.detach().contiguous().float()
+    B, T, F = Hmag.shape
+    if out is None:
+        out = torch.empty((B, T * hop), device=Hmag.device, dtype=torch.float32)
+        accumulate = False
+    elif out.shape != (B, T * hop) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("out must be a contiguous fp32 [B, T*hop] tensor")
+    if B == 0:
+        return out
+    if uniform is not None:
+        if tuple(uniform.shape) != (B, T, hop):
+            raise ValueError(f"uniform must be [B,T,hop] = {(B, T, hop)}, got {tuple(uniform.shape)}")
+        uniform = uniform.detach().to(device=Hmag.device, dtype=torch.float32).contiguous()
+    with torch.cuda.device(Hmag.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = _lib.lib().ddsp_noise_forward(Hmag.data_ptr(), None if uniform is None else uniform.data_ptr(),
+                                           out.data_ptr(), B, T, F, hop, seed, offset, 1 if accumulate else 0, stream)
+    _lib.check(rc, "ddsp_noise_forward")
+    return out
+
+
+class FilteredNoise(nn.Module):
+    def __init__(self, conf, rng: str = 'host', seed: int = 0):
+        super().__init__()
+        self.block_size = conf.hop_length
+        if rng not in ('host', 'device'):
+            raise ValueError("rng must be 'host' (torch CPU generator, reference-compatible) or 'device' (Philox)")
+        self.rng = rng
+        self.seed = seed
+        self._calls = 0
+
+    def forward(self, x, noise=None):
+        param = x['H']
+        B, T, _ = param.shape
+        if noise is None and self.rng == 'host':
+            noise = torch.rand(B, T, self.block_size)  # :44-48: CPU global generator, same shape and order
+        offset = 0
+        if noise is None:
+            quads = (self.block_size + 3) // 4
+            offset = self._calls * B * T * quads
+            self._calls += 1
+        return noise_forward(param, self.block_size, uniform=noise, seed=self.seed, offset=offset)

@@ -1,0 +1,72 @@
+"""Drop-in `OscillatorBank` (reference: model/ddsp/harmonic_oscillator.py:7-75) on the HIP kernels.
+
+Same constructor (`conf.n_harmonics / sample_rate / hop_length`, :11-13), same
+`forward(x)` / `live(x)` reading `x['f0'] [B,T,1]`, `x['c'] [B,T,H]`, `x['a'] [B,T,1]`
+(:57-75), same state-dict keys `harmonics` and `last_phases` (:15-22), same result as the
+reference evaluated on the CPU (the oracle BASELINE.json fixes) within 1e-5.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _dev_ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _check_inputs(f0, c, a):
+    if f0.dim() != 3 or c.dim() != 3 or a.dim() != 3 or f0.shape[-1] != 1 or a.shape[-1] != 1:
+        raise ValueError("expected f0 [B,T,1], c [B,T,H], a [B,T,1]")
+    if f0.shape[:2] != c.shape[:2] or a.shape[:2] != c.shape[:2]:
+        raise ValueError(f"batch/frame mismatch: f0 {tuple(f0.shape)}, c {tuple(c.shape)}, a {tuple(a.shape)}")
+    if not c.is_cuda:
+        raise _lib.DdspHipError("OscillatorBank runs on the GPU only (no CPU fallback): move the controls to cuda")
+
+
+def osc_forward(f0, c, a, hop: int, sample_rate: int, live_in=None, want_live_out=False, debug_phases=False):
+    """Raw launcher over the C ABI (include/ddsp_hip.h: ddsp_osc_forward). Returns (y, live_out, phi)."""
+    _check_inputs(f0, c, a)
+    f0 = f0.detach().contiguous().float()
+    c = c.detach().contiguous().float()
+    a = a.detach().contiguous().float()
+    B, T, H = c.shape
+    L = _lib.lib()
+    y = torch.empty((B, T * hop), device=c.device, dtype=torch.float32)
+    if B == 0:
+        return y, None, None
+    scratch = torch.empty(L.ddsp_osc_scratch_bytes(B, T, H), device=c.device, dtype=torch.uint8)
+    live_out = torch.empty(H, device=c.device, dtype=torch.float32) if want_live_out else None
+    phi = torch.empty((B, T * hop, H), device=c.device, dtype=torch.float32) if debug_phases else None
+    if live_in is not None:
+        live_in = live_in.detach().to(device=c.device, dtype=torch.float32).contiguous()
+    with torch.cuda.device(c.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = L.ddsp_osc_forward(f0.data_ptr(), c.data_ptr(), a.data_ptr(), y.data_ptr(), scratch.data_ptr(),
+                                _dev_ptr(live_in), _dev_ptr(live_out), _dev_ptr(phi), B, T, H, hop, sample_rate, stream)
+    _lib.check(rc, "ddsp_osc_forward")
+    return y, live_out, phi
+
+
+class OscillatorBank(nn.Module):
+    def __init__(self, conf):
+        super().__init__()
+        self.n_harmonics = conf.n_harmonics
+        self.sample_rate = conf.sample_rate
+        self.hop_size = conf.hop_length
+        # same (non-trainable) parameters, dtypes and names as the reference (:15-22) so that its
+        # checkpoints load with strict=True; `last_phases` starts int64 and becomes fp32 after live()
+        self.harmonics = nn.Parameter(torch.arange(1, self.n_harmonics + 1, step=1), requires_grad=False)
+        self.last_phases = nn.Parameter(torch.zeros_like(self.harmonics), requires_grad=False)
+
+    def forward(self, x):
+        y, _, _ = osc_forward(x['f0'], x['c'], x['a'], self.hop_size, self.sample_rate)
+        return y
+
+    def live(self, x):
+        y, last, _ = osc_forward(x['f0'], x['c'], x['a'], self.hop_size, self.sample_rate,
+                                 live_in=self.last_phases.data, want_live_out=True)
+        self.last_phases.data = last  # :72 (only batch row 0 carries state, as in the reference)
+        return y

@@ -1,0 +1,95 @@
+/*
+ * ddsp_hip.h -- C ABI of libddsp_hip.so: the MI355X (gfx950) DDSP synthesis hot path.
+ *
+ * The reference (kureta/ddsp-pytorch) has no FFI of its own: its hot path is two
+ * Python nn.Modules made of stock torch ops.  These entry points are what a binding
+ * for that path binds instead of those op sequences:
+ *
+ *   ddsp_osc_forward      replaces OscillatorBank.forward / .live
+ *                         (model/ddsp/harmonic_oscillator.py:57-62 and :64-75, i.e.
+ *                          prepare_harmonics :24-37, generate_phases :39-43, generate_signal :45-50)
+ *   ddsp_noise_forward    replaces FilteredNoise.forward
+ *                         (model/ddsp/filtered_noise.py:40-53, i.e. amp_to_impulse_response :7-22,
+ *                          fft_convolve :25-32, and the torch.rand draw :44-48)
+ *
+ * Conventions: plain pointers and sizes only (no torch types); every pointer is DEVICE memory
+ * unless said otherwise; tensors are dense row-major fp32 with the reference's shapes; nothing
+ * is allocated or synchronised inside (the caller passes scratch; launches are asynchronous on
+ * `stream`, a hipStream_t passed as void*; NULL = the default stream).  Return value: 0 on
+ * success, a hipError_t (> 0) if a launch failed, or a negative DDSP_E* code for bad
+ * arguments.  No exceptions cross the boundary.
+ */
+#ifndef DDSP_HIP_H
+#define DDSP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDSP_HIP_ABI_VERSION 1
+
+#define DDSP_EINVAL (-1)   /* null pointer / non-positive size */
+#define DDSP_ERANGE (-2)   /* shape outside what the kernels are built for */
+
+/* ABI version of the loaded library (== DDSP_HIP_ABI_VERSION it was built with). */
+int ddsp_hip_abi_version(void);
+
+/*
+ * Bytes of device scratch ddsp_osc_forward needs for a [B,T,H] problem:
+ * frame-rate increments fp32 [B,T,H] + normalised amplitudes fp32 [B,T,H] +
+ * frame-start phase accumulators fp64 [B,T,H]  (16*B*T*H bytes, 256-byte aligned parts).
+ */
+size_t ddsp_osc_scratch_bytes(int B, int T, int H);
+
+/*
+ * Harmonic oscillator bank (harmonic_oscillator.py:57-62; .live :64-75 when live_in != NULL).
+ *   f0 [B,T,1] Hz, c [B,T,H] harmonic amplitudes, a [B,T,1] loudness  ->  y [B, T*hop]
+ *   scratch        >= ddsp_osc_scratch_bytes(B,T,H) bytes, 256-byte aligned
+ *   live_in  [H]   nullable: phase offsets added to the first increment row of batch row 0 (:70)
+ *   live_out [H]   nullable: receives the last phase row of batch row 0 (:72); must not alias live_in
+ *   dbg_phi  [B,T*hop,H] nullable (tests only): the wrapped phases, bit-exact w.r.t. torch CPU
+ * Inputs are not modified.  Requires T*hop < 2^24 (exact fp32 sample indices).
+ */
+int ddsp_osc_forward(const float *f0, const float *c, const float *a, float *y, void *scratch,
+                     const float *live_in, float *live_out, float *dbg_phi,
+                     int B, int T, int H, int hop, int sample_rate, void *stream);
+
+/*
+ * Filtered noise (filtered_noise.py:40-53).
+ *   Hmag [B,T,F] filter magnitudes -> y [B, T*hop]; per frame: zero-phase IR (irfft, length 2(F-1)),
+ *   periodic-Hann window, re-wrapped to hop samples (cropped when hop < 2(F-1)), then the first hop
+ *   samples of the linear convolution with uniform noise in [-1,1); frames are concatenated.
+ *   uniform [B,T,hop] nullable: the U[0,1) draw (what torch.rand returned, filtered_noise.py:44-48).
+ *                      NULL => drawn on the device with Philox4x32-10 from (seed, offset); that stream is
+ *                      NOT the torch CPU generator's (documented in DESIGN.md).
+ *   accumulate != 0: y += noise instead of y = noise (fuses decoder.py:132 `harmonics + noise`).
+ */
+int ddsp_noise_forward(const float *Hmag, const float *uniform, float *y,
+                       int B, int T, int F, int hop, uint64_t seed, uint64_t offset,
+                       int accumulate, void *stream);
+
+/*
+ * Tuning hook (benchmarks only): force the number of harmonics each lane keeps in registers
+ * (one of 4,8,12,13,15,16,20,23,25); 0 restores the automatic choice.  Process-global, not
+ * thread-safe; results are identical for every setting.
+ */
+int ddsp_osc_set_tiling(int harmonics_per_lane);
+
+/*
+ * Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+ *   ddsp_profile_enable(capacity)  capacity > 0: pre-create that many event pairs and start recording one
+ *                                  pair around every kernel launch; capacity <= 0: stop and free them.
+ *   ddsp_profile_read(ids, ms, cap) HOST arrays; waits for the recorded events, returns how many records were
+ *                                  written (kernel id: 0 prep, 1 frame totals, 2 scan, 3 synth, 4 noise;
+ *                                  elapsed milliseconds) and resets the pool.  Never called from a launch path.
+ */
+int ddsp_profile_enable(int capacity);
+int ddsp_profile_read(int *kernel_ids, float *ms, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDSP_HIP_H */

@@ -1,0 +1,84 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/ddsp_hip.h declares
+(no compute calls without a GPU), argument validation, host logic, state-dict compatibility."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import ddsp_pytorch_amd as ddsp
+from ddsp_pytorch_amd import synthetic as syn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Conf:
+    def __init__(self, n_harmonics, sample_rate, hop_length):
+        self.n_harmonics, self.sample_rate, self.hop_length = n_harmonics, sample_rate, hop_length
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ddsp_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ddsp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    L = ctypes.CDLL(ddsp._lib.SO_PATH)
+    syms = declared_symbols()
+    assert set(syms) == set(ddsp._lib.EXPORTS)
+    for s in syms:
+        assert hasattr(L, s), s
+
+
+def test_abi_version_and_scratch_size():
+    L = ddsp._lib.lib()
+    assert L.ddsp_hip_abi_version() == 1
+    assert L.ddsp_osc_scratch_bytes(0, 1, 1) == 0
+    n = 64 * 500 * 100
+    assert L.ddsp_osc_scratch_bytes(64, 500, 100) >= 16 * n
+
+
+def test_argument_validation_without_gpu():
+    L = ddsp._lib.lib()
+    assert L.ddsp_osc_forward(None, None, None, None, None, None, None, None, 1, 1, 1, 1, 16000, None) == -1
+    assert L.ddsp_osc_forward(None, None, None, None, None, None, None, None, 0, 1, 1, 1, 16000, None) == 0  # empty batch
+    assert L.ddsp_noise_forward(None, None, None, 1, 1, 65, 128, 0, 0, 0, None) == -1
+    assert L.ddsp_osc_set_tiling(7) == -2 and L.ddsp_osc_set_tiling(0) == 0
+
+
+def test_module_boundary_matches_reference_contract():
+    osc = ddsp.OscillatorBank(Conf(60, 16000, 128))
+    sd = osc.state_dict()
+    assert list(sd) == ["harmonics", "last_phases"]
+    assert sd["harmonics"].dtype == torch.int64 and torch.equal(sd["harmonics"], torch.arange(1, 61))
+    assert sd["last_phases"].dtype == torch.int64 and not any(p.requires_grad for p in osc.parameters())
+    assert (osc.n_harmonics, osc.sample_rate, osc.hop_size) == (60, 16000, 128)
+    fn = ddsp.FilteredNoise(Conf(60, 16000, 128))
+    assert fn.block_size == 128 and len(fn.state_dict()) == 0
+    with pytest.raises(ddsp._lib.DdspHipError):
+        osc({"f0": torch.ones(1, 2, 1), "c": torch.ones(1, 2, 60), "a": torch.ones(1, 2, 1)})  # CPU tensors: no fallback
+    with pytest.raises(ValueError):
+        osc({"f0": torch.ones(1, 2), "c": torch.ones(1, 2, 60), "a": torch.ones(1, 2, 1)})
+
+
+def test_product_path_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "ddsp-pytorch_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                for needle in ("import oracle", "from oracle", "libddsp_oracle", "ddsp_oracle", "oracle/"):
+                    assert needle not in text, (f, needle)
+
+
+def test_synthetic_controls_ranges():
+    ctl = syn.make_controls(syn.CFG2, 1002, "all_live", batch=2)
+    assert ctl["f0"].shape == (2, 500, 1) and ctl["c"].shape == (2, 500, 100) and ctl["H"].shape == (2, 500, 65)
+    assert ctl["f0"].max() * 100 < 8000 and ctl["f0"].min() >= 39
+    assert all(v.dtype == np.float32 for v in ctl.values())
+    assert ctl["c"].min() >= 1e-7 and ctl["c"].max() <= 2.0 + 1e-6
+    mus = syn.make_controls(syn.CFG2, 1003, "musical", batch=2)["f0"]
+    assert 31.0 < mus.min() and mus.max() < 2006.0

@@ -75,3 +75,39 @@ def test_noise(path):
     y, ir = oracle.noise_forward(g["H"], g["uniform"], int(g["hop"]), debug=True)
     assert np.max(np.abs(ir - g["ir"])) <= 5e-7
     assert np.max(np.abs(y - g["y"])) <= 2e-6
+
+
+# ---- the torch-op restatement (what bench.py times as cpu_baseline) ---------------------------------
+import torch  # noqa: E402
+
+from oracle import torch_restatement as tr  # noqa: E402
+
+
+@pytest.mark.parametrize("name", OSC_INTERMEDIATE + ["g2b_osc_cfg1", "g3_osc_cfg2_musical"])
+def test_torch_restatement_osc_bitwise(name):
+    g = load_golden(name)
+    y, ph = tr.oscillator_bank(torch.from_numpy(g["f0"]), torch.from_numpy(g["c"]), torch.from_numpy(g["a"]),
+                               int(g["hop"]), int(g["sample_rate"]), return_phases=True)
+    assert np.array_equal(bits(y.numpy()), bits(g["y"]))
+    if "phi" in g:
+        assert np.array_equal(bits(ph.numpy()), bits(g["phi"]))
+
+
+def test_torch_restatement_live_bitwise():
+    g = load_golden("g7_osc_live")
+    state = torch.zeros(180, dtype=torch.float32)
+    for k in range(3):
+        y = tr.oscillator_bank(torch.from_numpy(g[f"f0_{k}"]), torch.from_numpy(g[f"c_{k}"]), torch.from_numpy(g[f"a_{k}"]),
+                               512, 44100, live_phase=state)
+        assert np.array_equal(bits(y.numpy()), bits(g[f"y_{k}"]))
+        assert np.array_equal(bits(state.numpy()), bits(g[f"last_phases_{k}"]))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "g8_noise_*.npz"))))
+def test_torch_restatement_noise_bitwise(path):
+    g = load_golden(os.path.basename(path)[:-4])
+    y = tr.filtered_noise(torch.from_numpy(g["H"]), int(g["hop"]), uniform=torch.from_numpy(g["uniform"]))
+    assert np.array_equal(bits(y.numpy()), bits(g["y"]))
+    torch.manual_seed(int(g["seed"]))
+    y2 = tr.filtered_noise(torch.from_numpy(g["H"]), int(g["hop"]))
+    assert np.array_equal(bits(y2.numpy()), bits(g["y"]))

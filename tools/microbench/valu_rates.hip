@@ -1,0 +1,159 @@
+// Microbenchmarks that size the oscillator kernel's design:
+//   (1) issue rate of the VALU instructions on its critical path, at 1/2/4/8 waves per SIMD;
+//   (2) accuracy of v_sin_f32 on the argument range the fast modulo produces.
+// Build: hipcc -O3 --offload-arch=gfx950 valu_rates.hip -o valu_rates.bin ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+constexpr int ITERS = 4096;
+constexpr int UNROLL = 16;  // independent instructions per loop iteration
+
+enum Op { FMA32, MUL32, PKFMA32, ADD64, FMA64, CVT_F64_F32, CVT_F32_F64, SIN32, FLOOR32, CNDMASK, MOVDPP, MIX };
+
+template <int OP>
+__global__ void __launch_bounds__(256) rate_kernel(float *out, float seed)
+{
+    float a = seed + threadIdx.x * 1e-3f, b = 1.0001f;
+    float f[UNROLL];
+    double d[UNROLL];
+    float2 p2[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) { f[u] = a + u; d[u] = (double)a + u; p2[u] = make_float2(a + u, a - u); }
+    float2 b2 = make_float2(b, b);
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (OP == FMA32) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[u]) : "v"(b), "v"(a));
+            if (OP == MUL32) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[u]) : "v"(b));
+            if (OP == PKFMA32) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p2[u]) : "v"(b2));
+            if (OP == ADD64) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[u]) : "v"((double)b));
+            if (OP == FMA64) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d[u]) : "v"((double)b));
+            if (OP == CVT_F64_F32) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[u]) : "v"(f[u]));
+            if (OP == CVT_F32_F64) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f[u]) : "v"(d[u]));
+            if (OP == SIN32) asm volatile("v_sin_f32 %0, %0" : "+v"(f[u]));
+            if (OP == FLOOR32) asm volatile("v_floor_f32 %0, %0" : "+v"(f[u]));
+            if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(f[u]) : "v"(b));
+            if (OP == MOVDPP) asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(f[u]));
+            if (OP == MIX) {
+                // the oscillator's per-harmonic-sample chain (12 instructions)
+                float t, P, q, r, s;
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(b), "v"(f[u]));
+                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(a), "v"(f[u]));
+                double dd;
+                asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(dd) : "v"(t));
+                asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[u]) : "v"(dd));
+                asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(P) : "v"(d[u]));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q) : "v"(P), "v"(b));
+                asm volatile("v_floor_f32 %0, %0" : "+v"(q));
+                asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(q), "v"(b), "v"(P));
+                asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r) : "v"(b));
+                asm volatile("v_sin_f32 %0, %1" : "=v"(s) : "v"(r));
+                asm volatile("v_fma_f32 %0, %1, %2, %2" : "=v"(t) : "v"(a), "v"(b));
+                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(f[u]) : "v"(t), "v"(s));
+            }
+        }
+    }
+    float acc = 0;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc += f[u] + (float)d[u] + p2[u].x + p2[u].y;
+    if (acc == 12345.678f) out[0] = acc;
+}
+
+template <int OP>
+void run(const char *name, int insts_per_u, float *dout)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int wps : {1, 2, 4, 8}) {  // waves per SIMD: blocks of 256 threads = 4 waves = 1 wave per SIMD of a CU
+        const int grid = 256 * wps;
+        hipLaunchKernelGGL(rate_kernel<OP>, dim3(grid), dim3(256), 0, 0, dout, 1.0f);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(rate_kernel<OP>, dim3(grid), dim3(256), 0, 0, dout, 1.0f);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double winst = (double)grid * 4 * ITERS * UNROLL * insts_per_u;  // wave-instructions
+        const double per_simd_ns = ms * 1e6 / (winst / (256.0 * 4));           // ns per wave-instruction per SIMD
+        printf("%-14s waves/SIMD=%d  %.3f ms  %.2f ns per wave-instr per SIMD (= %.2f cyc @2.4GHz)  %.2f T lane-ops/s\n", name, wps, ms,
+               per_simd_ns, per_simd_ns * 2.4, winst * 64 / (ms * 1e-3) / 1e12);
+    }
+}
+
+// ---- v_sin_f32 accuracy ---------------------------------------------------------------------------
+__global__ void sin_err_kernel(unsigned lo_bits, unsigned n, int negate, float *max_err, float *arg_at_max, int variant)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    float e = 0.0f, arg = 0.0f;
+    for (unsigned k = i; k < n; k += gridDim.x * blockDim.x) {
+        float r = __uint_as_float(lo_bits + k);
+        if (negate) r = -r;
+        float s;
+        if (variant == 0) s = __builtin_amdgcn_sinf(r * 0.15915494309189535f);
+        else if (variant == 1) s = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r * 0.15915494309189535f));
+        else if (variant == 2) s = __sinf(r);
+        else s = sinf(r);
+        const float err = fabsf((float)((double)s - sin((double)r)));
+        if (err > e) { e = err; arg = r; }
+    }
+    // block max
+    __shared__ float se[256], sa[256];
+    se[threadIdx.x] = e; sa[threadIdx.x] = arg;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o && se[threadIdx.x + o] > se[threadIdx.x]) { se[threadIdx.x] = se[threadIdx.x + o]; sa[threadIdx.x] = sa[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { max_err[blockIdx.x] = se[0]; arg_at_max[blockIdx.x] = sa[0]; }
+}
+
+void sin_accuracy()
+{
+    const int blocks = 2048;
+    float *dme, *dam;
+    CK(hipMalloc(&dme, blocks * 4)); CK(hipMalloc(&dam, blocks * 4));
+    std::vector<float> me(blocks), am(blocks);
+    const char *names[] = {"v_sin(r/2pi)", "v_sin(fract(r/2pi))", "__sinf", "sinf (ocml)"};
+    struct Range { float lo, hi; int neg; } ranges[] = {{1e-6f, 7.9f, 0}, {1e-6f, 1.7f, 1}, {0.0f, 6.2831855f, 0}};
+    for (int variant = 0; variant < 4; ++variant)
+        for (auto rg : ranges) {
+            unsigned lo, hi;
+            memcpy(&lo, &rg.lo, 4); memcpy(&hi, &rg.hi, 4);
+            hipLaunchKernelGGL(sin_err_kernel, dim3(blocks), dim3(256), 0, 0, lo, hi - lo + 1, rg.neg, dme, dam, variant);
+            CK(hipMemcpy(me.data(), dme, blocks * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(am.data(), dam, blocks * 4, hipMemcpyDeviceToHost));
+            float e = 0, a = 0;
+            for (int b = 0; b < blocks; ++b) if (me[b] > e) { e = me[b]; a = am[b]; }
+            printf("sin accuracy %-22s r in %s[%g, %g] (every fp32): max abs err %.3e at r=%.9g\n", names[variant], rg.neg ? "-" : "", rg.lo, rg.hi, e, a);
+        }
+}
+
+int main()
+{
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    printf("device %s  CUs %d  clock %d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
+    float *dout;
+    CK(hipMalloc(&dout, 1024));
+    sin_accuracy();
+    run<FMA32>("v_fma_f32", 1, dout);
+    run<MUL32>("v_mul_f32", 1, dout);
+    run<PKFMA32>("v_pk_fma_f32", 1, dout);
+    run<ADD64>("v_add_f64", 1, dout);
+    run<FMA64>("v_fma_f64", 1, dout);
+    run<CVT_F64_F32>("v_cvt_f64_f32", 1, dout);
+    run<CVT_F32_F64>("v_cvt_f32_f64", 1, dout);
+    run<SIN32>("v_sin_f32", 1, dout);
+    run<FLOOR32>("v_floor_f32", 1, dout);
+    run<CNDMASK>("v_cndmask_b32", 1, dout);
+    run<MOVDPP>("v_add_f32_dpp", 1, dout);
+    run<MIX>("osc chain x12", 12, dout);
+    return 0;
+}
