@@ -26,7 +26,8 @@ namespace {
 constexpr float kTwoPi32 = 6.2831854820251465f;     // fl32(2*pi): the modulus the reference uses (:34,:42)
 constexpr float kInvTwoPi32 = 0.15915493667125702f; // fl32(1/fl32(2*pi))
 constexpr float kRevPerRad = 0.15915494309189535f;  // 1/(2*pi) for v_sin_f32 (argument in revolutions)
-constexpr float kFastPhaseLimit = 1.0e7f;           // fast modulo is exact while floor(P/2pi) < 2^21
+constexpr float kFastPhaseLimit = 1.0e7f;           // fast modulo is exact while P/2pi32 < 2^21
+constexpr float kRoundMagic = 12582912.0f;          // 1.5*2^23: (x + magic) - magic = rint(x) for |x| < 2^22
 
 struct OscParams {
     const float *f0, *c, *a;
@@ -36,6 +37,7 @@ struct OscParams {
     const float *live_in;
     float *live_out;
     float *dbg_phi;
+    int *redo_flag;   // scratch: set by the FAST synth kernel when a wavefront needs the EXACT one
     int B, T, H, R;
     int logG;
     int force_exact;
@@ -85,6 +87,7 @@ __global__ void __launch_bounds__(256) osc_prep_kernel(OscParams p)
 {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *p.redo_flag = 0;
     if (row >= (long)p.B * p.T) return;
     const float f = p.f0[row];
     const float *crow = p.c + row * p.H;
@@ -135,6 +138,9 @@ __global__ void __launch_bounds__(64 * kScanWaves) osc_scan_kernel(OscParams p)
 
 // ---- frame kernels -----------------------------------------------------------------------------
 enum { MODE_TOTALS = 0, MODE_SYNTH = 1 };
+// FAST: production path.  EXACT: bit-exact modulo (libm fmodf), live state and debug outputs; it also
+// repairs the frames the FAST synth kernel declined (phases outside the fast modulo's exact range).
+enum { VAR_FAST = 0, VAR_EXACT = 1 };
 
 template <int K>
 struct FrameState {
@@ -157,9 +163,9 @@ __device__ __forceinline__ int split_index(int t, int R, float scale)
     return m;
 }
 
-template <int K, int MODE, bool EXACT, bool LIVE>
-__device__ __forceinline__ void walk_segment(const OscParams &p, FrameState<K> &st, const float (&lp)[K], int b, int t,
-                                             int j, bool active, int i0, int i1, int n_beg, int n_end)
+template <int K, int MODE>
+__device__ __forceinline__ void load_segment(const OscParams &p, FrameState<K> &st, int b, int j, int i0, int i1,
+                                             float &L0, float &L1)
 {
     const int G = 1 << p.logG;
     const long rowbase = (long)b * p.T;
@@ -180,42 +186,95 @@ __device__ __forceinline__ void walk_segment(const OscParams &p, FrameState<K> &
             st.da[m] = u1 - u0;
         }
     }
-    float L0 = 0.0f, L1 = 0.0f;
+    L0 = L1 = 0.0f;
     if (MODE == MODE_SYNTH) {
         L0 = p.a[rowbase + i0];
         L1 = p.a[rowbase + i1];
     }
+}
+
+// F.interpolate(linear, align_corners=False) weights of output sample i against source frame i0: App. A item 4
+__device__ __forceinline__ void upsample_weights(float scale, int i, float i0f, float &w0, float &w1)
+{
+    float src = __fmaf_rn(scale, (float)i + 0.5f, -0.5f);
+    src = fmaxf(src, 0.0f);
+    w1 = fminf(fmaxf(src - i0f, 0.0f), 1.0f);
+    w0 = 1.0f - w1;
+}
+
+// Production walk over samples [n_beg, n_end) of frame t, written stage by stage over the lane's K harmonics
+// so that the K independent dependency chains interleave.
+template <int K, int MODE>
+__device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st, int b, int t, int j, bool active,
+                                          int i0, int i1, int n_beg, int n_end)
+{
+    float L0, L1;
+    load_segment<K, MODE>(p, st, b, j, i0, i1, L0, L1);
+    const float i0f = (float)i0;
+    float *yrow = p.y + (long)b * p.T * p.R;
+    for (int n = n_beg; n < n_end; ++n) {
+        const int i = t * p.R + n;
+        float w0, w1;
+        upsample_weights(p.scale, i, i0f, w0, w1);
+        float v[K];
+#pragma unroll
+        for (int m = 0; m < K; ++m) v[m] = __fmaf_rn(w0, st.x0[m], w1 * st.x1[m]);  // fl32(fma(w0,x[i0],fl32(w1*x[i1])))
+#pragma unroll
+        for (int m = 0; m < K; ++m) st.acc[m] += (double)v[m];                        // :41 double accumulator
+        if (MODE == MODE_SYNTH) {
+#pragma unroll
+            for (int m = 0; m < K; ++m) v[m] = (float)st.acc[m];                      // ... rounded to fp32 per sample
+#pragma unroll
+            for (int m = 0; m < K; ++m) {
+                // P - q*2pi32 is exact in fp32 for q = rint(P/2pi32 +- 0.25) < 2^21: r in (-4.8, 4.8).  Taking the
+                // nearest multiple instead of the floor changes sin(r) by <= |2pi32 - 2pi| = 1.75e-7.
+                const float q = __fmaf_rn(v[m], kInvTwoPi32, kRoundMagic) - kRoundMagic;
+                v[m] = __fmaf_rn(-q, kTwoPi32, v[m]);                                 // :42
+            }
+#pragma unroll
+            for (int m = 0; m < K; ++m) v[m] = __builtin_amdgcn_sinf(v[m] * kRevPerRad);  // v_sin_f32 (revolutions)
+            float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+            for (int m = 0; m < K; ++m) {
+                const float A = __fmaf_rn(w1, st.da[m], st.a0[m]);
+                if (m & 1) s1 = __fmaf_rn(A, v[m], s1); else s0 = __fmaf_rn(A, v[m], s0);  // :48-49
+            }
+            const float sum = group_sum(s0 + s1, p.logG);
+            const float L = __fmaf_rn(w0, L0, w1 * L1);
+            if (j == 0 && active) yrow[i] = L * sum;
+        }
+    }
+}
+
+// Reference-exact walk: libm fmodf modulo, live offsets (:70), live state and debug phase outputs.
+template <int K, int MODE>
+__device__ __forceinline__ void walk_exact(const OscParams &p, FrameState<K> &st, const float (&lp)[K], int b, int t,
+                                           int j, bool active, int i0, int i1, int n_beg, int n_end)
+{
+    const int G = 1 << p.logG;
+    float L0, L1;
+    load_segment<K, MODE>(p, st, b, j, i0, i1, L0, L1);
     const float i0f = (float)i0;
     const long N = (long)p.T * p.R;
     for (int n = n_beg; n < n_end; ++n) {
         const int i = t * p.R + n;
-        // F.interpolate(linear, align_corners=False): SURVEY App. A item 4
-        float src = __fmaf_rn(p.scale, (float)i + 0.5f, -0.5f);
-        src = fmaxf(src, 0.0f);
-        const float lam = fminf(fmaxf(src - i0f, 0.0f), 1.0f);
-        const float w1 = lam, w0 = 1.0f - lam;
+        float w0, w1;
+        upsample_weights(p.scale, i, i0f, w0, w1);
         float sum = 0.0f;
 #pragma unroll
         for (int m = 0; m < K; ++m) {
-            float inc = __fmaf_rn(w0, st.x0[m], w1 * st.x1[m]);  // fl32(fma(w0, x[i0], fl32(w1*x[i1])))
-            if (LIVE) inc = (i == 0) ? inc + lp[m] : inc;          // :70 (lp is zero except for b == 0)
-            st.acc[m] += (double)inc;                             // :41 torch CPU cumsum: double accumulator
+            const int h = j + m * G;
+            float inc = __fmaf_rn(w0, st.x0[m], w1 * st.x1[m]);
+            inc = (i == 0) ? inc + lp[m] : inc;                   // :70 (lp is zero unless live and b == 0)
+            st.acc[m] += (double)inc;
             if (MODE == MODE_SYNTH) {
-                const float P = (float)st.acc[m];                 // ... rounded to fp32 per sample
-                float r;
-                if (EXACT) {
-                    r = remainder_two_pi(P);                      // :42
-                    if (p.dbg_phi && active && (j + m * G) < p.H) p.dbg_phi[((long)b * N + i) * p.H + j + m * G] = r;
-                    if (LIVE && p.live_out && active && b == 0 && i == N - 1 && (j + m * G) < p.H) p.live_out[j + m * G] = r;
-                } else {
-                    // exact P - q*2pi32 with q within +-1 of floor(P/2pi32): r in (-1.6, 7.9); the missing
-                    // +-2pi32 fix-up changes sin(r) by <= |2pi32 - 2pi| = 1.75e-7
-                    const float q = floorf(P * kInvTwoPi32);
-                    r = __fmaf_rn(-q, kTwoPi32, P);
-                }
-                const float s = __builtin_amdgcn_sinf(r * kRevPerRad);  // v_sin_f32
+                const float P = (float)st.acc[m];
+                const float r = remainder_two_pi(P);              // :42, exact
+                if (p.dbg_phi && active && h < p.H) p.dbg_phi[((long)b * N + i) * p.H + h] = r;
+                if (p.live_out && active && b == 0 && i == N - 1 && h < p.H) p.live_out[h] = r;  // :72
+                const float s = __builtin_amdgcn_sinf(r * kRevPerRad);
                 const float A = __fmaf_rn(w1, st.da[m], st.a0[m]);
-                sum = __fmaf_rn(A, s, sum);                        // :48-49
+                sum = __fmaf_rn(A, s, sum);
             }
         }
         if (MODE == MODE_SYNTH) {
@@ -226,9 +285,10 @@ __device__ __forceinline__ void walk_segment(const OscParams &p, FrameState<K> &
     }
 }
 
-template <int K, int MODE, bool LIVE>
+template <int K, int MODE, int VARIANT>
 __global__ void __launch_bounds__(256) osc_frame_kernel(OscParams p)
 {
+    if (MODE == MODE_SYNTH && VARIANT == VAR_EXACT && !p.force_exact && *p.redo_flag == 0) return;
     const int G = 1 << p.logG;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const int j = threadIdx.x & (G - 1);
@@ -238,22 +298,15 @@ __global__ void __launch_bounds__(256) osc_frame_kernel(OscParams p)
     if (!active) f = nframes - 1;  // keep the lanes alive for the cross-lane sums; their stores are masked
     const int b = (int)(f / p.T);
     const int t = (int)(f - (long)b * p.T);
+    const int ia = max(t - 1, 0), ib = t, ic = min(t + 1, p.T - 1);
 
     FrameState<K> st;
-    float lp[K];
     bool fast = true;
 #pragma unroll
     for (int m = 0; m < K; ++m) {
         const int h = j + m * G;
-        const bool ok = h < p.H;
-        lp[m] = (LIVE && ok && b == 0 && p.live_in) ? p.live_in[h] : 0.0f;
-        if (MODE == MODE_SYNTH) {
-            st.acc[m] = ok ? p.ph0[((long)b * p.T + t) * p.H + h] : 0.0;
-        } else {
-            st.acc[m] = 0.0;
-        }
+        st.acc[m] = (MODE == MODE_SYNTH && h < p.H) ? p.ph0[((long)b * p.T + t) * p.H + h] : 0.0;
     }
-    const int ia = max(t - 1, 0), ib = t, ic = min(t + 1, p.T - 1);
     if (MODE == MODE_SYNTH) {
         // The fast modulo needs 0 <= P < kFastPhaseLimit over the whole frame: increments of the three
         // bracketing frames non-negative (phases then grow monotonically) and the end-of-frame bound small.
@@ -263,22 +316,30 @@ __global__ void __launch_bounds__(256) osc_frame_kernel(OscParams p)
             const int h = j + m * G;
             if (h < p.H) {
                 const float xa = wb[(long)ia * p.H + h], xb = wb[(long)ib * p.H + h], xc = wb[(long)ic * p.H + h];
-                const float xm = fmaxf(fmaxf(xa, xb), xc);
-                const float bound = (float)st.acc[m] + (float)p.R * xm * 1.0001f + fabsf(lp[m]);
-                const bool okm = (xa >= 0.0f) && (xb >= 0.0f) && (xc >= 0.0f) && (st.acc[m] >= 0.0) && (lp[m] >= 0.0f) &&
-                                 (bound < kFastPhaseLimit);
-                fast = fast && okm;
+                const float bound = (float)st.acc[m] + (float)p.R * fmaxf(fmaxf(xa, xb), xc) * 1.0001f;
+                fast = fast && (xa >= 0.0f) && (xb >= 0.0f) && (xc >= 0.0f) && (st.acc[m] >= 0.0) && (bound < kFastPhaseLimit);
             }
         }
-        if (LIVE || p.force_exact) fast = false;
+        fast = __all(fast);  // wave-uniform
+        if (VARIANT == VAR_FAST && !fast) {
+            if ((threadIdx.x & 63) == 0) atomicOr(p.redo_flag, 1);  // the EXACT kernel that follows redoes this wavefront
+            return;
+        }
+        if (VARIANT == VAR_EXACT && fast && !p.force_exact) return;  // already written by the FAST kernel
     }
     const int split = split_index(t, p.R, p.scale);
-    if (MODE == MODE_SYNTH && !LIVE && __all(fast)) {
-        walk_segment<K, MODE, false, false>(p, st, lp, b, t, j, active, ia, ib, 0, split);
-        walk_segment<K, MODE, false, false>(p, st, lp, b, t, j, active, ib, ic, split, p.R);
+    if (VARIANT == VAR_FAST) {
+        walk_fast<K, MODE>(p, st, b, t, j, active, ia, ib, 0, split);
+        walk_fast<K, MODE>(p, st, b, t, j, active, ib, ic, split, p.R);
     } else {
-        walk_segment<K, MODE, true, LIVE>(p, st, lp, b, t, j, active, ia, ib, 0, split);
-        walk_segment<K, MODE, true, LIVE>(p, st, lp, b, t, j, active, ib, ic, split, p.R);
+        float lp[K];
+#pragma unroll
+        for (int m = 0; m < K; ++m) {
+            const int h = j + m * G;
+            lp[m] = (h < p.H && b == 0 && p.live_in) ? p.live_in[h] : 0.0f;
+        }
+        walk_exact<K, MODE>(p, st, lp, b, t, j, active, ia, ib, 0, split);
+        walk_exact<K, MODE>(p, st, lp, b, t, j, active, ib, ic, split, p.R);
     }
     if (MODE == MODE_TOTALS && active) {
 #pragma unroll
@@ -324,11 +385,12 @@ hipError_t launch_frames(const OscParams &p, hipStream_t s)
 {
     const long lanes = ((long)p.B * p.T) << p.logG;
     const unsigned grid = (unsigned)((lanes + 255) / 256);
+    const bool live = p.live_in || p.live_out;
     int slot = ddsp_prof::begin(ddsp_prof::TOTALS, s);
     if (p.live_in) {
-        hipLaunchKernelGGL((osc_frame_kernel<K, MODE_TOTALS, true>), dim3(grid), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((osc_frame_kernel<K, MODE_TOTALS, VAR_EXACT>), dim3(grid), dim3(256), 0, s, p);
     } else {
-        hipLaunchKernelGGL((osc_frame_kernel<K, MODE_TOTALS, false>), dim3(grid), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((osc_frame_kernel<K, MODE_TOTALS, VAR_FAST>), dim3(grid), dim3(256), 0, s, p);
     }
     ddsp_prof::end(slot, s);
     const int tiles = (p.H + 63) / 64;
@@ -336,12 +398,11 @@ hipError_t launch_frames(const OscParams &p, hipStream_t s)
     hipLaunchKernelGGL(osc_scan_kernel, dim3((unsigned)(p.B * tiles)), dim3(64 * kScanWaves), 0, s, p);
     ddsp_prof::end(slot, s);
     slot = ddsp_prof::begin(ddsp_prof::SYNTH, s);
-    if (p.live_in || p.live_out) {
-        hipLaunchKernelGGL((osc_frame_kernel<K, MODE_SYNTH, true>), dim3(grid), dim3(256), 0, s, p);
-    } else {
-        hipLaunchKernelGGL((osc_frame_kernel<K, MODE_SYNTH, false>), dim3(grid), dim3(256), 0, s, p);
-    }
+    if (!live && !p.force_exact)
+        hipLaunchKernelGGL((osc_frame_kernel<K, MODE_SYNTH, VAR_FAST>), dim3(grid), dim3(256), 0, s, p);
     ddsp_prof::end(slot, s);
+    // exits at once unless a wavefront of the FAST kernel raised redo_flag (or exactness is forced)
+    hipLaunchKernelGGL((osc_frame_kernel<K, MODE_SYNTH, VAR_EXACT>), dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -364,7 +425,7 @@ extern "C" size_t ddsp_osc_scratch_bytes(int B, int T, int H)
 {
     if (B <= 0 || T <= 0 || H <= 0) return 0;
     const size_t n = (size_t)B * T * H;
-    return 2 * align256(n * sizeof(float)) + align256(n * sizeof(double));
+    return 2 * align256(n * sizeof(float)) + align256(n * sizeof(double)) + 256;
 }
 
 extern "C" int ddsp_osc_forward(const float *f0, const float *c, const float *a, float *y, void *scratch,
@@ -385,10 +446,11 @@ extern "C" int ddsp_osc_forward(const float *f0, const float *c, const float *a,
     p.w = (float *)base;
     p.amp = (float *)(base + align256(n * sizeof(float)));
     p.ph0 = (double *)(base + 2 * align256(n * sizeof(float)));
+    p.redo_flag = (int *)(base + 2 * align256(n * sizeof(float)) + align256(n * sizeof(double)));
     p.live_in = live_in; p.live_out = live_out; p.dbg_phi = dbg_phi;
     p.B = B; p.T = T; p.H = H; p.R = hop;
     p.logG = tl.logG;
-    p.force_exact = (dbg_phi != nullptr) ? 1 : 0;
+    p.force_exact = (dbg_phi != nullptr || live_in != nullptr || live_out != nullptr) ? 1 : 0;
     p.scale = (float)(1.0 / (double)hop);
     p.nyquist = (float)(sample_rate / 2);
     p.sr = (float)sample_rate;
