@@ -20,6 +20,8 @@
 
 namespace {
 
+int g_force_generic = 0;  // ddsp_noise_set_generic: tests exercise the one-frame-per-workgroup kernel
+
 struct NoiseParams {
     const float *Hm;
     const float *u;
@@ -106,6 +108,168 @@ __global__ void __launch_bounds__(256) noise_frame_kernel(NoiseParams p)
     }
 }
 
+
+// ---- batched kernel: 64 frames per workgroup, lane = frame ------------------------------------------
+// Used when hop % 8 == 0 and the tile fits in LDS.  512 threads = 8 wavefronts.
+//   phase 0  H tile -> LDS transposed [k][frame]; cos table
+//   phase 1  zero-phase IR by direct inverse real DFT, 4 frames per thread, using
+//            cos(2*pi*k*(S/2-n)/S) = (-1)^k cos(2*pi*k*n/S): one pass over k yields z[n] and z[S/2-n];
+//            windowed and re-wrapped straight into kern[frame][j]
+//   phase 2  noise tile (injected draw or Philox) -> xs[frame][8 + m] (8 leading zeros = causal padding)
+//   phase 3  truncated convolution, register blocked: a wavefront owns output chunks c and C-1-c
+//            (8 samples each, balanced triangle) of 64 frames; per 8 taps: 6 ds_read_b128, 64 FMAs
+constexpr int kFB = 64;        // frames per workgroup
+constexpr int kNT = 512;       // threads per workgroup
+constexpr int kHS = kFB + 4;   // row stride of the transposed H tile (keeps float4 rows aligned, spreads banks)
+
+__device__ __forceinline__ int kern_stride(int R) { return R + 4; }
+__device__ __forceinline__ int xs_stride(int R) { return R + 12; }
+
+__global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int S = p.S, R = p.R, F = p.F, half = S >> 1;
+    const int KS = kern_stride(R), XS = xs_stride(R);
+    float *ct = smem;                                   // [S] (rounded up to a multiple of 4)
+    float *kern = ct + ((S + 3) & ~3);                  // [64][KS]
+    float *un = kern + kFB * KS;                        // union: Hs [F][64]  |  xs [64][XS]
+    float *Hs = un, *xs = un;
+    const int tid = threadIdx.x;
+    const long frame0 = (long)blockIdx.x * kFB;
+    const long nframes = (long)p.B * p.T;
+    const int nf = (int)min((long)kFB, nframes - frame0);
+
+    // phase 0
+    for (int e = tid; e < kFB * F; e += kNT) {
+        const int f = e / F, k = e - f * F;              // coalesced global read, transposed (padded) LDS write
+        Hs[k * kHS + f] = (f < nf) ? p.Hm[(frame0 + f) * F + k] : 0.0f;
+    }
+    for (int m = tid; m < S; m += kNT) ct[m] = cospif((float)(2 * m) / (float)S);
+    for (int e = tid; e < kFB * KS; e += kNT) kern[e] = 0.0f;
+    __syncthreads();
+
+    // phase 1
+    const int taps = min(S, R);
+    const float invS = 1.0f / (float)S;
+    const int npair = half / 2 + 1;                     // n = 0 .. half/2, paired with half - n
+    for (int item = tid; item < npair * (kFB / 4); item += kNT) {
+        const int fq = item / npair, n = item - fq * npair;  // n fastest: the H reads of a wavefront broadcast
+        float e0 = 0, e1 = 0, e2 = 0, e3 = 0, o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+        int idx = 0;
+        for (int k = 1; k < half; ++k) {
+            idx += n;
+            if (idx >= S) idx -= S;
+            const float c = ct[idx];
+            const float4 h = *reinterpret_cast<const float4 *>(&Hs[k * kHS + 4 * fq]);
+            if (k & 1) { o0 = __fmaf_rn(h.x, c, o0); o1 = __fmaf_rn(h.y, c, o1); o2 = __fmaf_rn(h.z, c, o2); o3 = __fmaf_rn(h.w, c, o3); }
+            else       { e0 = __fmaf_rn(h.x, c, e0); e1 = __fmaf_rn(h.y, c, e1); e2 = __fmaf_rn(h.z, c, e2); e3 = __fmaf_rn(h.w, c, e3); }
+        }
+        const float4 h0 = *reinterpret_cast<const float4 *>(&Hs[4 * fq]);
+        const float4 hn = *reinterpret_cast<const float4 *>(&Hs[half * kHS + 4 * fq]);
+        const float ev[4] = {e0, e1, e2, e3}, ov[4] = {o0, o1, o2, o3};
+        const float h0v[4] = {h0.x, h0.y, h0.z, h0.w}, hnv[4] = {hn.x, hn.y, hn.z, hn.w};
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int nn = side ? half - n : n;          // z index in [0, half]
+            if (side && nn == n) break;
+            const float sg = (nn & 1) ? -1.0f : 1.0f;
+            // z[nn] lands (windowed) where the rolled/padded/rolled buffer puts samples nn and S-nn of the irfft
+#pragma unroll
+            for (int wrap = 0; wrap < 2; ++wrap) {
+                // roll(z, S/2)[src] holds z[(src + S/2) % S]; z[nn] = z[S - nn] sits at src = nn + S/2 and S/2 - nn
+                int src;
+                if (!wrap) { if (nn == half) continue; src = nn + half; }
+                else       { if (nn == 0) continue;    src = half - nn; }
+                if (src >= taps) continue;
+                const float win = 0.5f - 0.5f * ct[src];      // torch.hann_window(S), periodic
+                int jj = (src - half) % R;                    // roll(-S/2) on the length-R buffer
+                if (jj < 0) jj += R;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float z = __fmaf_rn(2.0f, side ? (ev[q] - ov[q]) : (ev[q] + ov[q]), h0v[q] + sg * hnv[q]) * invS;
+                    kern[(4 * fq + q) * KS + jj] = z * win;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // phase 2 (overwrites the H tile)
+    for (int e = tid; e < kFB * 8; e += kNT) xs[(e >> 3) * XS + (e & 7)] = 0.0f;
+    if (p.u) {
+        for (int e = tid; e < kFB * R; e += kNT) {
+            const int f = e / R, m = e - f * R;
+            xs[f * XS + 8 + m] = (f < nf) ? p.u[(frame0 + f) * R + m] * 2.0f - 1.0f : 0.0f;
+        }
+    } else {
+        const int quads = R >> 2;                        // R % 8 == 0 here
+        for (int e = tid; e < kFB * quads; e += kNT) {
+            const int f = e / quads, q = e - f * quads;
+            const uint64_t ctr = p.offset + (uint64_t)(frame0 + f) * (uint64_t)quads + (uint64_t)q;
+            uint32_t r[4];
+            philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r);
+            float4 v;
+            v.x = (float)(r[0] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+            v.y = (float)(r[1] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+            v.z = (float)(r[2] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+            v.w = (float)(r[3] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+            *reinterpret_cast<float4 *>(&xs[f * XS + 8 + 4 * q]) = v;
+        }
+    }
+    __syncthreads();
+
+    // phase 3
+    const int lane = tid & 63, wv = tid >> 6;
+    const int C = R >> 3;
+    const float *krow = kern + lane * KS;
+    const float *xrow = xs + lane * XS + 8;
+    float *yrow = p.y + (frame0 + lane) * R;
+    for (int pr = wv; 2 * pr < C; pr += kNT / 64) {
+#pragma unroll 1
+        for (int side = 0; side < 2; ++side) {
+            const int c = side ? C - 1 - pr : pr;
+            if (side && c == pr) break;
+            const int n0 = c << 3;
+            float acc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = 0.0f;
+            for (int j = 0; j <= n0; j += 8) {
+                const float4 ka = *reinterpret_cast<const float4 *>(krow + j);
+                const float4 kb = *reinterpret_cast<const float4 *>(krow + j + 4);
+                const float4 xa = *reinterpret_cast<const float4 *>(xrow + n0 - j - 8);
+                const float4 xb = *reinterpret_cast<const float4 *>(xrow + n0 - j - 4);
+                const float4 xc = *reinterpret_cast<const float4 *>(xrow + n0 - j);
+                const float4 xd = *reinterpret_cast<const float4 *>(xrow + n0 - j + 4);
+                const float kv[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+                const float xw[16] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w, xd.x, xd.y, xd.z, xd.w};
+#pragma unroll
+                for (int v = 0; v < 8; ++v)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc[u] = __fmaf_rn(kv[v], xw[8 + u - v], acc[u]);
+            }
+            if (lane < nf) {
+                float4 lo = make_float4(acc[0], acc[1], acc[2], acc[3]), hi = make_float4(acc[4], acc[5], acc[6], acc[7]);
+                float4 *dst = reinterpret_cast<float4 *>(yrow + n0);
+                if (p.accumulate) {
+                    const float4 a = dst[0], b = dst[1];
+                    lo.x += a.x; lo.y += a.y; lo.z += a.z; lo.w += a.w;
+                    hi.x += b.x; hi.y += b.y; hi.z += b.z; hi.w += b.w;
+                }
+                dst[0] = lo;
+                dst[1] = hi;
+            }
+        }
+    }
+}
+
+size_t batched_lds_bytes(int F, int R)
+{
+    const int S = 2 * (F - 1);
+    const size_t ua = (size_t)kHS * F, ub = (size_t)kFB * (R + 12);
+    const size_t un = ua > ub ? ua : ub;
+    return sizeof(float) * (((S + 3) & ~3) + (size_t)kFB * (R + 4) + un);
+}
+
 }  // namespace
 
 extern "C" int ddsp_noise_forward(const float *Hmag, const float *uniform, float *y, int B, int T, int F, int hop,
@@ -117,10 +281,32 @@ extern "C" int ddsp_noise_forward(const float *Hmag, const float *uniform, float
     p.Hm = Hmag; p.u = uniform; p.y = y;
     p.B = B; p.T = T; p.F = F; p.R = hop; p.S = 2 * (F - 1);
     p.seed = seed; p.offset = offset; p.accumulate = accumulate;
+    if ((long)B * T >= (1L << 31)) return DDSP_ERANGE;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t blds = batched_lds_bytes(F, hop);
+    if (!g_force_generic && hop % 8 == 0 && blds <= 160 * 1024 && ((uintptr_t)y % 16) == 0) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void *)noise_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        const long blocks = ((long)B * T + kFB - 1) / kFB;
+        const int slot = ddsp_prof::begin(ddsp_prof::NOISE, s);
+        hipLaunchKernelGGL(noise_batched_kernel, dim3((unsigned)blocks), dim3(kNT), blds, s, p);
+        ddsp_prof::end(slot, s);
+        return (int)hipGetLastError();
+    }
     const size_t lds = sizeof(float) * ((size_t)F + p.S + 2 * (size_t)hop);
-    if (lds > 64 * 1024 || (long)B * T >= (1L << 31)) return DDSP_ERANGE;
-    const int slot = ddsp_prof::begin(ddsp_prof::NOISE, (hipStream_t)stream);
-    hipLaunchKernelGGL(noise_frame_kernel, dim3((unsigned)((long)B * T)), dim3(256), lds, (hipStream_t)stream, p);
-    ddsp_prof::end(slot, (hipStream_t)stream);
+    if (lds > 64 * 1024) return DDSP_ERANGE;
+    const int slot = ddsp_prof::begin(ddsp_prof::NOISE, s);
+    hipLaunchKernelGGL(noise_frame_kernel, dim3((unsigned)((long)B * T)), dim3(256), lds, s, p);
+    ddsp_prof::end(slot, s);
     return (int)hipGetLastError();
+}
+
+extern "C" int ddsp_noise_set_generic(int on)
+{
+    g_force_generic = on ? 1 : 0;
+    return 0;
 }

@@ -78,6 +78,10 @@ int ddsp_noise_forward(const float *Hmag, const float *uniform, float *y,
  */
 int ddsp_osc_set_tiling(int harmonics_per_lane);
 
+/* Test hook: non-zero forces the generic one-frame-per-workgroup noise kernel (any hop) instead of the
+ * batched 64-frames-per-workgroup one (hop % 8 == 0, tile fits LDS).  Same results within rounding. */
+int ddsp_noise_set_generic(int on);
+
 /*
  * Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  *   ddsp_profile_enable(capacity)  capacity > 0: pre-create that many event pairs and start recording one

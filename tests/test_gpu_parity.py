@@ -187,3 +187,25 @@ def test_cpu_tensors_fail_loudly():
     g = load_golden("g1_osc_tiny")
     with pytest.raises(ddsp._lib.DdspHipError):
         ddsp.osc_forward(torch.from_numpy(g["f0"]), torch.from_numpy(g["c"]), torch.from_numpy(g["a"]), 64, 16000)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "g8_noise_*.npz"))))
+def test_noise_generic_kernel(path):
+    g = load_golden(os.path.basename(path)[:-4])
+    L = ddsp._lib.lib()
+    L.ddsp_noise_set_generic(1)
+    try:
+        y = ddsp.noise_forward(dev(g["H"]), int(g["hop"]), uniform=dev(g["uniform"]))
+    finally:
+        L.ddsp_noise_set_generic(0)
+    assert np.max(np.abs(y.cpu().numpy() - g["y"])) <= 2e-6
+
+
+@pytest.mark.parametrize("hop,nf,B,T", [(128, 65, 3, 70), (64, 65, 2, 33), (256, 129, 1, 65), (128, 33, 1, 64), (8, 5, 2, 9), (136, 7, 1, 5)])
+def test_noise_vs_oracle_ragged_tiles(hop, nf, B, T):
+    rng = np.random.default_rng(hop + nf)
+    H = syn.controller_range(rng.standard_normal((B, T, nf), dtype=np.float32))
+    u = rng.random((B, T, hop), dtype=np.float32)
+    ref = oracle.noise_forward(H, u, hop)
+    y = ddsp.noise_forward(dev(H), hop, uniform=dev(u))
+    assert np.max(np.abs(y.cpu().numpy() - ref)) <= 2e-6
