@@ -29,6 +29,7 @@ struct NoiseParams {
     int B, T, F, R, S;
     uint64_t seed, offset;
     int accumulate;
+    int ablate;  // debug/timing only: bit1 skips the IR phase, bit2 the convolution (results are then wrong)
 };
 
 // Philox4x32-10 (Salmon et al. 2011), counter = (c0,c1,0,0), key = seed.
@@ -145,50 +146,68 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
         Hs[k * kHS + f] = (f < nf) ? p.Hm[(frame0 + f) * F + k] : 0.0f;
     }
     for (int m = tid; m < S; m += kNT) ct[m] = cospif((float)(2 * m) / (float)S);
-    for (int e = tid; e < kFB * KS; e += kNT) kern[e] = 0.0f;
+    if (S < R)                                          // otherwise phase 1 writes every tap
+        for (int e = tid; e < kFB * KS; e += kNT) kern[e] = 0.0f;
     __syncthreads();
 
     // phase 1
     const int taps = min(S, R);
     const float invS = 1.0f / (float)S;
-    const int npair = half / 2 + 1;                     // n = 0 .. half/2, paired with half - n
-    for (int item = tid; item < npair * (kFB / 4); item += kNT) {
-        const int fq = item / npair, n = item - fq * npair;  // n fastest: the H reads of a wavefront broadcast
-        float e0 = 0, e1 = 0, e2 = 0, e3 = 0, o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-        int idx = 0;
-        for (int k = 1; k < half; ++k) {
-            idx += n;
-            if (idx >= S) idx -= S;
-            const float c = ct[idx];
-            const float4 h = *reinterpret_cast<const float4 *>(&Hs[k * kHS + 4 * fq]);
-            if (k & 1) { o0 = __fmaf_rn(h.x, c, o0); o1 = __fmaf_rn(h.y, c, o1); o2 = __fmaf_rn(h.z, c, o2); o3 = __fmaf_rn(h.w, c, o3); }
-            else       { e0 = __fmaf_rn(h.x, c, e0); e1 = __fmaf_rn(h.y, c, e1); e2 = __fmaf_rn(h.z, c, e2); e3 = __fmaf_rn(h.w, c, e3); }
+    // z[nn] (nn in [0, S/2], = z[S-nn]) of frame f goes, windowed, where roll/pad/roll put samples nn and S-nn
+    auto emit = [&](int f, int nn, float z) {
+#pragma unroll
+        for (int wrap = 0; wrap < 2; ++wrap) {
+            // roll(z, S/2)[src] holds z[(src + S/2) % S]: z[nn] sits at src = nn + S/2 and src = S/2 - nn
+            int src;
+            if (!wrap) { if (nn == half) continue; src = nn + half; }
+            else       { if (nn == 0) continue;    src = half - nn; }
+            if (src >= taps) continue;
+            const float win = 0.5f - 0.5f * ct[src];      // torch.hann_window(S), periodic
+            int jj = (src - half) % R;                    // roll(-S/2) on the length-R buffer
+            if (jj < 0) jj += R;
+            kern[f * KS + jj] = z * win;
         }
-        const float4 h0 = *reinterpret_cast<const float4 *>(&Hs[4 * fq]);
-        const float4 hn = *reinterpret_cast<const float4 *>(&Hs[half * kHS + 4 * fq]);
-        const float ev[4] = {e0, e1, e2, e3}, ov[4] = {o0, o1, o2, o3};
-        const float h0v[4] = {h0.x, h0.y, h0.z, h0.w}, hnv[4] = {hn.x, hn.y, hn.z, hn.w};
+    };
+    if (!(p.ablate & 2)) {
+        // n = 0 and n = S/2 need no cosines: plain and alternating sums, 8 lanes per frame
+        {
+            const int f = tid >> 3, part = tid & 7;
+            float e = 0.0f, o = 0.0f;
+            for (int k = 1 + part; k < half; k += 8) {
+                const float h = Hs[k * kHS + f];
+                if (k & 1) o += h; else e += h;
+            }
 #pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const int nn = side ? half - n : n;          // z index in [0, half]
-            if (side && nn == n) break;
-            const float sg = (nn & 1) ? -1.0f : 1.0f;
-            // z[nn] lands (windowed) where the rolled/padded/rolled buffer puts samples nn and S-nn of the irfft
+            for (int m = 1; m < 8; m <<= 1) { e += __shfl_xor(e, m); o += __shfl_xor(o, m); }
+            if (part == 0) {
+                const float h0 = Hs[f], hn = Hs[half * kHS + f];
+                emit(f, 0, __fmaf_rn(2.0f, e + o, h0 + hn) * invS);
+                if (half > 0) emit(f, half, __fmaf_rn(2.0f, e - o, h0 + ((half & 1) ? -hn : hn)) * invS);
+            }
+        }
+        // n = 1 .. S/4 paired with S/2 - n: cos(2 pi k (S/2 - n) / S) = (-1)^k cos(2 pi k n / S)
+        const int nmain = half / 2;
+        for (int item = tid; item < nmain * (kFB / 4); item += kNT) {
+            const int fq = item / nmain, n = 1 + item - fq * nmain;  // n fastest: a wavefront's H reads broadcast
+            float ev[4] = {0, 0, 0, 0}, ov[4] = {0, 0, 0, 0};
+            int idx = 0;
+            for (int k = 1; k < half; ++k) {
+                idx += n;
+                if (idx >= S) idx -= S;
+                const float c = ct[idx];
+                const float4 h = *reinterpret_cast<const float4 *>(&Hs[k * kHS + 4 * fq]);
+                if (k & 1) { ov[0] = __fmaf_rn(h.x, c, ov[0]); ov[1] = __fmaf_rn(h.y, c, ov[1]); ov[2] = __fmaf_rn(h.z, c, ov[2]); ov[3] = __fmaf_rn(h.w, c, ov[3]); }
+                else       { ev[0] = __fmaf_rn(h.x, c, ev[0]); ev[1] = __fmaf_rn(h.y, c, ev[1]); ev[2] = __fmaf_rn(h.z, c, ev[2]); ev[3] = __fmaf_rn(h.w, c, ev[3]); }
+            }
+            const float4 h0 = *reinterpret_cast<const float4 *>(&Hs[4 * fq]);
+            const float4 hn = *reinterpret_cast<const float4 *>(&Hs[half * kHS + 4 * fq]);
+            const float h0v[4] = {h0.x, h0.y, h0.z, h0.w}, hnv[4] = {hn.x, hn.y, hn.z, hn.w};
+            const int n2 = half - n;
+            const float sg1 = (n & 1) ? -1.0f : 1.0f, sg2 = (n2 & 1) ? -1.0f : 1.0f;
 #pragma unroll
-            for (int wrap = 0; wrap < 2; ++wrap) {
-                // roll(z, S/2)[src] holds z[(src + S/2) % S]; z[nn] = z[S - nn] sits at src = nn + S/2 and S/2 - nn
-                int src;
-                if (!wrap) { if (nn == half) continue; src = nn + half; }
-                else       { if (nn == 0) continue;    src = half - nn; }
-                if (src >= taps) continue;
-                const float win = 0.5f - 0.5f * ct[src];      // torch.hann_window(S), periodic
-                int jj = (src - half) % R;                    // roll(-S/2) on the length-R buffer
-                if (jj < 0) jj += R;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float z = __fmaf_rn(2.0f, side ? (ev[q] - ov[q]) : (ev[q] + ov[q]), h0v[q] + sg * hnv[q]) * invS;
-                    kern[(4 * fq + q) * KS + jj] = z * win;
-                }
+            for (int q = 0; q < 4; ++q) {
+                emit(4 * fq + q, n, __fmaf_rn(2.0f, ev[q] + ov[q], h0v[q] + sg1 * hnv[q]) * invS);
+                if (n2 != n) emit(4 * fq + q, n2, __fmaf_rn(2.0f, ev[q] - ov[q], h0v[q] + sg2 * hnv[q]) * invS);
             }
         }
     }
@@ -224,7 +243,7 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
     const float *krow = kern + lane * KS;
     const float *xrow = xs + lane * XS + 8;
     float *yrow = p.y + (frame0 + lane) * R;
-    for (int pr = wv; 2 * pr < C; pr += kNT / 64) {
+    for (int pr = wv; 2 * pr < ((p.ablate & 4) ? 0 : C); pr += kNT / 64) {
 #pragma unroll 1
         for (int side = 0; side < 2; ++side) {
             const int c = side ? C - 1 - pr : pr;
@@ -240,6 +259,7 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
                 const float4 xb = *reinterpret_cast<const float4 *>(xrow + n0 - j - 4);
                 const float4 xc = *reinterpret_cast<const float4 *>(xrow + n0 - j);
                 const float4 xd = *reinterpret_cast<const float4 *>(xrow + n0 - j + 4);
+                asm volatile("" ::"v"(xa.x));  // keep the (unused) first lane alive so the window stays 4 x ds_read_b128
                 const float kv[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
                 const float xw[16] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w, xd.x, xd.y, xd.z, xd.w};
 #pragma unroll
@@ -280,11 +300,11 @@ extern "C" int ddsp_noise_forward(const float *Hmag, const float *uniform, float
     NoiseParams p;
     p.Hm = Hmag; p.u = uniform; p.y = y;
     p.B = B; p.T = T; p.F = F; p.R = hop; p.S = 2 * (F - 1);
-    p.seed = seed; p.offset = offset; p.accumulate = accumulate;
+    p.seed = seed; p.offset = offset; p.accumulate = accumulate; p.ablate = g_force_generic & ~1;
     if ((long)B * T >= (1L << 31)) return DDSP_ERANGE;
     hipStream_t s = (hipStream_t)stream;
     const size_t blds = batched_lds_bytes(F, hop);
-    if (!g_force_generic && hop % 8 == 0 && blds <= 160 * 1024 && ((uintptr_t)y % 16) == 0) {
+    if (!(g_force_generic & 1) && hop % 8 == 0 && blds <= 160 * 1024 && ((uintptr_t)y % 16) == 0) {
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute((const void *)noise_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -307,6 +327,6 @@ extern "C" int ddsp_noise_forward(const float *Hmag, const float *uniform, float
 
 extern "C" int ddsp_noise_set_generic(int on)
 {
-    g_force_generic = on ? 1 : 0;
+    g_force_generic = on;
     return 0;
 }

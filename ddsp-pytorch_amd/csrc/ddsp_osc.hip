@@ -2,17 +2,21 @@
 // model/ddsp/harmonic_oscillator.py:24-75 (prepare_harmonics, rescale, generate_phases,
 // generate_signal, forward, live).  Written from the arithmetic spec in SURVEY.md App. A.
 //
-// Decomposition:
-//   osc_prep_kernel    frame rate: w[b,t,k] = fl32(fl32(k*f0*2pi)/sr), amp = masked c / sum      (:26-35)
-//   osc_frame_kernel<MODE_TOTALS>  per (b,t): exact fp64 sum of the hop upsampled increments      (:36,:41)
-//   osc_scan_kernel    exclusive scan of those totals along t -> phase accumulator at frame start (:41)
-//   osc_frame_kernel<MODE_SYNTH>   per (b,t): re-walk the frame sample by sample                  (:41-49)
+// Decomposition, three launches (+ one that normally exits at once):
+//   osc_totals_kernel   per (b,t): frame-rate increments w = fl32(fl32(k*f0*2pi)/sr) recomputed from f0 for the
+//                       three bracketing frames, masked/normalised amplitudes of frame t (:26-35), the exact fp64 sum
+//                       of the frame's `hop` upsampled increments (:36,:41), and -- through LDS -- the exclusive scan
+//                       of those sums over the workgroup's 256/G consecutive frames (a "superblock") + its total
+//   osc_supscan_kernel  exclusive scan of the superblock totals along t (tiny)
+//   osc_synth_kernel    per (b,t): start phase = superblock prefix + local prefix; re-walk the frame sample by sample:
+//                       increment, fp64 accumulate, round to fp32, modulo 2pi32, sin, amplitude, sum over harmonics (:41-49)
+//   osc_synth_kernel<EXACT>  bit-exact modulo / live state / debug phases; also redoes the wavefronts the fast kernel
+//                       declined (phases outside the fast modulo's exact range) -- exits immediately otherwise
 //
-// Work mapping of the two frame kernels: a GROUP of G = 2^logG adjacent lanes owns one (b,t) frame;
-// each lane keeps K harmonics (k = j + G*m) entirely in registers -- fp64 accumulator, the two
-// bracketing frame-rate increments and amplitudes -- and walks the frame's samples sequentially, so
-// the phase recurrence needs NO cross-lane scan; the only cross-lane traffic is a log2(G)-step DPP
-// sum per output sample.  64/G frames per wavefront, 256/G per workgroup.
+// Work mapping of the frame kernels: a GROUP of G = 2^logG adjacent lanes owns one (b,t) frame; each lane keeps
+// K harmonics (k = j + G*m) entirely in registers -- fp64 accumulator, the two bracketing frame-rate increments
+// and amplitudes -- and walks the frame's samples sequentially, so the phase recurrence needs NO cross-lane scan;
+// the only cross-lane traffic is a log2(G)-step DPP sum per output sample.  64/G frames per wavefront.
 //
 // Compile with -ffp-contract=off: every rounding point below is part of the parity contract.
 #include <hip/hip_runtime.h>
@@ -32,14 +36,16 @@ constexpr float kRoundMagic = 12582912.0f;          // 1.5*2^23: (x + magic) - m
 struct OscParams {
     const float *f0, *c, *a;
     float *y;
-    float *w, *amp;   // scratch [B,T,H]
-    double *ph0;      // scratch [B,T,H]: frame totals, then (in place) exclusive scan
+    float *w, *amp;   // scratch [B,T,H]: written by the totals kernel (row t), read by the synth kernels
+    double *loc;      // scratch [B,T,H]: exclusive prefix of the frame totals inside the frame's superblock
+    double *sup;      // scratch [B,NSB,H]: superblock totals, then (in place) their exclusive scan along t
+    int *redo_flag;   // scratch: set by the FAST synth kernel when a wavefront needs the EXACT one
     const float *live_in;
     float *live_out;
     float *dbg_phi;
-    int *redo_flag;   // scratch: set by the FAST synth kernel when a wavefront needs the EXACT one
     int B, T, H, R;
-    int logG;
+    int logG;         // lanes per frame group
+    int NSB;          // superblocks per batch row = ceil(T / (256 >> logG))
     int force_exact;
     float scale;      // fl32(1/R): F.interpolate's source-index scale
     float nyquist;    // float(sample_rate // 2)
@@ -53,8 +59,8 @@ __device__ __forceinline__ float dpp_mov(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
-// Sum over the G = 2^logG lanes of a group (groups are G-aligned).  Result valid in every lane for
-// G <= 16 and at least in the group's first lane for G = 32, 64.
+// Sum over the G = 2^logG lanes of a group (groups are G-aligned); every lane of the group gets the total
+// (each step is a symmetric exchange).
 __device__ __forceinline__ float group_sum(float v, int logG)
 {
     if (logG >= 1) v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
@@ -81,72 +87,17 @@ __device__ __forceinline__ float remainder_two_pi(float p)
     return r;
 }
 
-// ---- frame-rate preparation (harmonic_oscillator.py:26-35) ---------------------------------
-// One wavefront per (b,t) row.
-__global__ void __launch_bounds__(256) osc_prep_kernel(OscParams p)
-{
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *p.redo_flag = 0;
-    if (row >= (long)p.B * p.T) return;
-    const float f = p.f0[row];
-    const float *crow = p.c + row * p.H;
-    float s = 0.0f;
-    for (int h = lane; h < p.H; h += 64) {
-        const float hz = (float)(h + 1) * f;
-        s += (hz > p.nyquist) ? 0.0f : crow[h];
-    }
-    s = wave_sum(s);
-    for (int h = lane; h < p.H; h += 64) {
-        const float hz = (float)(h + 1) * f;                 // :26-29
-        const float a0 = (hz > p.nyquist) ? 0.0f : crow[h];  // :31-32 (strict >, integer Nyquist)
-        p.amp[row * p.H + h] = a0 / s;                       // :33 (0/0 = NaN when all masked)
-        const float rad = hz * kTwoPi32;                     // :34
-        p.w[row * p.H + h] = rad / p.sr;                     // :35 true division
-    }
-}
-
-// ---- exclusive scan of the frame totals along t ----------------------------------------------
-// One workgroup per (b, 64-harmonic tile); kScanWaves wavefronts split the T axis.
-constexpr int kScanWaves = 8;
-__global__ void __launch_bounds__(64 * kScanWaves) osc_scan_kernel(OscParams p)
-{
-    __shared__ double part[kScanWaves][64];
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    const int tiles = (p.H + 63) >> 6;
-    const int b = blockIdx.x / tiles;
-    const int h = (blockIdx.x - b * tiles) * 64 + lane;
-    const bool ok = h < p.H;
-    const int chunk = (p.T + kScanWaves - 1) / kScanWaves;
-    const int t0 = min(wv * chunk, p.T), t1 = min(t0 + chunk, p.T);
-    double *col = p.ph0 + (long)b * p.T * p.H + (ok ? h : 0);
-    double s = 0.0;
-    if (ok)
-        for (int t = t0; t < t1; ++t) s += col[(long)t * p.H];
-    part[wv][lane] = s;
-    __syncthreads();
-    double run = 0.0;
-    for (int v = 0; v < wv; ++v) run += part[v][lane];
-    if (ok)
-        for (int t = t0; t < t1; ++t) {
-            const double v = col[(long)t * p.H];
-            col[(long)t * p.H] = run;
-            run += v;
-        }
-}
-
 // ---- frame kernels -----------------------------------------------------------------------------
 enum { MODE_TOTALS = 0, MODE_SYNTH = 1 };
 // FAST: production path.  EXACT: bit-exact modulo (libm fmodf), live state and debug outputs; it also
-// repairs the frames the FAST synth kernel declined (phases outside the fast modulo's exact range).
+// repairs the wavefronts the FAST synth kernel declined (phases outside the fast modulo's exact range).
 enum { VAR_FAST = 0, VAR_EXACT = 1 };
 
 template <int K>
 struct FrameState {
     double acc[K];
     float x0[K], x1[K];  // frame-rate increments at the bracketing frames i0, i1
-    float a0[K], da[K];  // amplitude at i0 and (amp[i1] - amp[i0])
+    float a0[K], da[K];  // amplitude at i0 and (amp[i1] - amp[i0])   (synth only)
 };
 
 // First sample index n in [0,R) of frame t whose interpolation source index is >= t, i.e. where
@@ -163,9 +114,26 @@ __device__ __forceinline__ int split_index(int t, int R, float scale)
     return m;
 }
 
-template <int K, int MODE>
-__device__ __forceinline__ void load_segment(const OscParams &p, FrameState<K> &st, int b, int j, int i0, int i1,
-                                             float &L0, float &L1)
+// F.interpolate(linear, align_corners=False) weights of output sample i against source frame i0: App. A item 4
+__device__ __forceinline__ void upsample_weights(float scale, int i, float i0f, float &w0, float &w1)
+{
+    float src = __fmaf_rn(scale, (float)i + 0.5f, -0.5f);
+    src = fmaxf(src, 0.0f);
+    w1 = fminf(fmaxf(src - i0f, 0.0f), 1.0f);
+    w0 = 1.0f - w1;
+}
+
+// rad/sample of harmonic h (0-based) at fundamental f: two roundings and a true division (:26-35, App. A item 3)
+__device__ __forceinline__ float frame_increment(int h, float f, float sr)
+{
+    const float hz = (float)(h + 1) * f;
+    const float rad = hz * kTwoPi32;
+    return rad / sr;
+}
+
+template <int K>
+__device__ __forceinline__ void load_synth_segment(const OscParams &p, FrameState<K> &st, int b, int j, int i0, int i1,
+                                                   float &L0, float &L1)
 {
     const int G = 1 << p.logG;
     const long rowbase = (long)b * p.T;
@@ -179,37 +147,21 @@ __device__ __forceinline__ void load_segment(const OscParams &p, FrameState<K> &
         const bool ok = h < p.H;
         st.x0[m] = ok ? w0row[h] : 0.0f;
         st.x1[m] = ok ? w1row[h] : 0.0f;
-        if (MODE == MODE_SYNTH) {
-            const float u0 = ok ? a0row[h] : 0.0f;
-            const float u1 = ok ? a1row[h] : 0.0f;
-            st.a0[m] = u0;
-            st.da[m] = u1 - u0;
-        }
+        const float u0 = ok ? a0row[h] : 0.0f;
+        const float u1 = ok ? a1row[h] : 0.0f;
+        st.a0[m] = u0;
+        st.da[m] = u1 - u0;
     }
-    L0 = L1 = 0.0f;
-    if (MODE == MODE_SYNTH) {
-        L0 = p.a[rowbase + i0];
-        L1 = p.a[rowbase + i1];
-    }
-}
-
-// F.interpolate(linear, align_corners=False) weights of output sample i against source frame i0: App. A item 4
-__device__ __forceinline__ void upsample_weights(float scale, int i, float i0f, float &w0, float &w1)
-{
-    float src = __fmaf_rn(scale, (float)i + 0.5f, -0.5f);
-    src = fmaxf(src, 0.0f);
-    w1 = fminf(fmaxf(src - i0f, 0.0f), 1.0f);
-    w0 = 1.0f - w1;
+    L0 = p.a[rowbase + i0];
+    L1 = p.a[rowbase + i1];
 }
 
 // Production walk over samples [n_beg, n_end) of frame t, written stage by stage over the lane's K harmonics
 // so that the K independent dependency chains interleave.
 template <int K, int MODE>
 __device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st, int b, int t, int j, bool active,
-                                          int i0, int i1, int n_beg, int n_end)
+                                          int i0, float L0, float L1, int n_beg, int n_end)
 {
-    float L0, L1;
-    load_segment<K, MODE>(p, st, b, j, i0, i1, L0, L1);
     const float i0f = (float)i0;
     float *yrow = p.y + (long)b * p.T * p.R;
     for (int n = n_beg; n < n_end; ++n) {
@@ -249,11 +201,9 @@ __device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st,
 // Reference-exact walk: libm fmodf modulo, live offsets (:70), live state and debug phase outputs.
 template <int K, int MODE>
 __device__ __forceinline__ void walk_exact(const OscParams &p, FrameState<K> &st, const float (&lp)[K], int b, int t,
-                                           int j, bool active, int i0, int i1, int n_beg, int n_end)
+                                           int j, bool active, int i0, float L0, float L1, int n_beg, int n_end)
 {
     const int G = 1 << p.logG;
-    float L0, L1;
-    load_segment<K, MODE>(p, st, b, j, i0, i1, L0, L1);
     const float i0f = (float)i0;
     const long N = (long)p.T * p.R;
     for (int n = n_beg; n < n_end; ++n) {
@@ -285,10 +235,124 @@ __device__ __forceinline__ void walk_exact(const OscParams &p, FrameState<K> &st
     }
 }
 
-template <int K, int MODE, int VARIANT>
-__global__ void __launch_bounds__(256) osc_frame_kernel(OscParams p)
+// ---- pass 1: frame totals + superblock-local exclusive scan ----------------------------------------
+// One workgroup = one superblock = 256/G consecutive frames of ONE batch row (grid = B * NSB).
+template <int K, bool LIVE>
+__global__ void __launch_bounds__(256) osc_totals_kernel(OscParams p)
 {
-    if (MODE == MODE_SYNTH && VARIANT == VAR_EXACT && !p.force_exact && *p.redo_flag == 0) return;
+    extern __shared__ double tot_s[];  // [FPB][H]
+    const int G = 1 << p.logG, FPB = 256 >> p.logG;
+    const int b = blockIdx.x / p.NSB, sb = blockIdx.x - b * p.NSB;
+    const int fl = threadIdx.x >> p.logG, j = threadIdx.x & (G - 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *p.redo_flag = 0;
+    int t = sb * FPB + fl;
+    const bool active = t < p.T;
+    if (!active) t = p.T - 1;
+    const int ia = max(t - 1, 0), ib = t;
+    const long rowbase = (long)b * p.T;
+    const float fb = p.f0[rowbase + ib];
+
+    FrameState<K> st;
+    float xc[K], lp[K];
+    // Increments of the superblock's frames (+ one halo row on each side) go through LDS so that every
+    // (frame, harmonic) costs ONE true division; the three bracketing rows are then read back.
+    float *w_s = reinterpret_cast<float *>(tot_s + (size_t)FPB * p.H);  // [(FPB + 2)][H]
+    {
+        const float *crow = p.c + (rowbase + t) * p.H;
+        float a0[K];
+        float s = 0.0f;
+#pragma unroll
+        for (int m = 0; m < K; ++m) {
+            const int h = j + m * G;
+            const bool ok = h < p.H;
+            const float hz = (float)(h + 1) * fb;
+            a0[m] = (ok && !(hz > p.nyquist)) ? crow[h] : 0.0f;   // :31-32 strict >, integer Nyquist
+            s += a0[m];
+        }
+        s = group_sum(s, p.logG);                                 // any summation order: App. A item 2
+        const float rs = 1.0f / s;                                // amp = a0 * (1/s): <= 1 ulp from a0/s (:33); 0 * inf = NaN
+#pragma unroll
+        for (int m = 0; m < K; ++m) {
+            const int h = j + m * G;
+            if (h < p.H) {
+                const float wv = frame_increment(h, fb, p.sr);
+                w_s[(fl + 1) * p.H + h] = wv;
+                if (active) {
+                    p.amp[(rowbase + t) * p.H + h] = a0[m] * rs;
+                    p.w[(rowbase + t) * p.H + h] = wv;
+                }
+            }
+        }
+        for (int e = threadIdx.x; e < 2 * p.H; e += 256) {        // halo rows: frame before / after the superblock
+            const int side = e >= p.H, h = e - side * p.H;
+            const int row = side ? min(sb * FPB + FPB, p.T - 1) : max(sb * FPB - 1, 0);
+            w_s[(side ? FPB + 1 : 0) * p.H + h] = frame_increment(h, p.f0[rowbase + row], p.sr);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+        const int h = j + m * G;
+        const bool ok = h < p.H;
+        st.acc[m] = 0.0;
+        st.x0[m] = ok ? w_s[fl * p.H + h] : 0.0f;
+        st.x1[m] = ok ? w_s[(fl + 1) * p.H + h] : 0.0f;
+        xc[m] = ok ? w_s[(fl + 2) * p.H + h] : 0.0f;
+        lp[m] = (LIVE && ok && b == 0 && p.live_in) ? p.live_in[h] : 0.0f;
+    }
+    const int split = split_index(t, p.R, p.scale);
+    if (LIVE) {
+        walk_exact<K, MODE_TOTALS>(p, st, lp, b, t, j, active, ia, 0.0f, 0.0f, 0, split);
+    } else {
+        walk_fast<K, MODE_TOTALS>(p, st, b, t, j, active, ia, 0.0f, 0.0f, 0, split);
+    }
+#pragma unroll
+    for (int m = 0; m < K; ++m) { st.x0[m] = st.x1[m]; st.x1[m] = xc[m]; }
+    if (LIVE) {
+        walk_exact<K, MODE_TOTALS>(p, st, lp, b, t, j, active, ib, 0.0f, 0.0f, split, p.R);
+    } else {
+        walk_fast<K, MODE_TOTALS>(p, st, b, t, j, active, ib, 0.0f, 0.0f, split, p.R);
+    }
+    // exclusive scan over the superblock's frames, one thread per harmonic column (exact: fp64 sums of fp32 values)
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+        const int h = j + m * G;
+        if (h < p.H) tot_s[fl * p.H + h] = active ? st.acc[m] : 0.0;
+    }
+    __syncthreads();
+    const int nvalid = min(FPB, p.T - sb * FPB);
+    for (int h = threadIdx.x; h < p.H; h += 256) {
+        double run = 0.0;
+        double *dst = p.loc + (rowbase + (long)sb * FPB) * p.H + h;
+        for (int f = 0; f < nvalid; ++f) {
+            const double v = tot_s[f * p.H + h];
+            dst[(long)f * p.H] = run;
+            run += v;
+        }
+        p.sup[((long)b * p.NSB + sb) * p.H + h] = run;
+    }
+}
+
+// ---- pass 2: exclusive scan of the superblock totals along t (B*H independent columns, NSB steps) -------
+__global__ void __launch_bounds__(256) osc_supscan_kernel(OscParams p)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)p.B * p.H) return;
+    const int b = (int)(idx / p.H), h = (int)(idx - (long)b * p.H);
+    double *col = p.sup + (long)b * p.NSB * p.H + h;
+    double run = 0.0;
+    for (int s = 0; s < p.NSB; ++s) {
+        const double v = col[(long)s * p.H];
+        col[(long)s * p.H] = run;
+        run += v;
+    }
+}
+
+// ---- pass 3: synthesis ------------------------------------------------------------------------------
+template <int K, int VARIANT>
+__global__ void __launch_bounds__(256) osc_synth_kernel(OscParams p)
+{
+    if (VARIANT == VAR_EXACT && !p.force_exact && *p.redo_flag == 0) return;
     const int G = 1 << p.logG;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const int j = threadIdx.x & (G - 1);
@@ -299,38 +363,37 @@ __global__ void __launch_bounds__(256) osc_frame_kernel(OscParams p)
     const int b = (int)(f / p.T);
     const int t = (int)(f - (long)b * p.T);
     const int ia = max(t - 1, 0), ib = t, ic = min(t + 1, p.T - 1);
+    const int sb = t / (256 >> p.logG);
 
     FrameState<K> st;
     bool fast = true;
+    const float *wb = p.w + (long)b * p.T * p.H;
 #pragma unroll
     for (int m = 0; m < K; ++m) {
         const int h = j + m * G;
-        st.acc[m] = (MODE == MODE_SYNTH && h < p.H) ? p.ph0[((long)b * p.T + t) * p.H + h] : 0.0;
-    }
-    if (MODE == MODE_SYNTH) {
-        // The fast modulo needs 0 <= P < kFastPhaseLimit over the whole frame: increments of the three
-        // bracketing frames non-negative (phases then grow monotonically) and the end-of-frame bound small.
-        const float *wb = p.w + (long)b * p.T * p.H;
-#pragma unroll
-        for (int m = 0; m < K; ++m) {
-            const int h = j + m * G;
-            if (h < p.H) {
-                const float xa = wb[(long)ia * p.H + h], xb = wb[(long)ib * p.H + h], xc = wb[(long)ic * p.H + h];
-                const float bound = (float)st.acc[m] + (float)p.R * fmaxf(fmaxf(xa, xb), xc) * 1.0001f;
-                fast = fast && (xa >= 0.0f) && (xb >= 0.0f) && (xc >= 0.0f) && (st.acc[m] >= 0.0) && (bound < kFastPhaseLimit);
-            }
+        st.acc[m] = 0.0;
+        if (h < p.H) {
+            st.acc[m] = p.loc[((long)b * p.T + t) * p.H + h] + p.sup[((long)b * p.NSB + sb) * p.H + h];
+            // The fast modulo needs 0 <= P < kFastPhaseLimit over the whole frame: increments of the three
+            // bracketing frames non-negative (phases then grow monotonically) and the end-of-frame bound small.
+            const float xa = wb[(long)ia * p.H + h], xb = wb[(long)ib * p.H + h], xc = wb[(long)ic * p.H + h];
+            const float bound = (float)st.acc[m] + (float)p.R * fmaxf(fmaxf(xa, xb), xc) * 1.0001f;
+            fast = fast && (xa >= 0.0f) && (xb >= 0.0f) && (xc >= 0.0f) && (st.acc[m] >= 0.0) && (bound < kFastPhaseLimit);
         }
-        fast = __all(fast);  // wave-uniform
-        if (VARIANT == VAR_FAST && !fast) {
-            if ((threadIdx.x & 63) == 0) atomicOr(p.redo_flag, 1);  // the EXACT kernel that follows redoes this wavefront
-            return;
-        }
-        if (VARIANT == VAR_EXACT && fast && !p.force_exact) return;  // already written by the FAST kernel
     }
+    fast = __all(fast);  // wave-uniform
+    if (VARIANT == VAR_FAST && !fast) {
+        if ((threadIdx.x & 63) == 0) atomicOr(p.redo_flag, 1);  // the EXACT kernel that follows redoes this wavefront
+        return;
+    }
+    if (VARIANT == VAR_EXACT && fast && !p.force_exact) return;  // already written by the FAST kernel
     const int split = split_index(t, p.R, p.scale);
+    float L0, L1;
     if (VARIANT == VAR_FAST) {
-        walk_fast<K, MODE>(p, st, b, t, j, active, ia, ib, 0, split);
-        walk_fast<K, MODE>(p, st, b, t, j, active, ib, ic, split, p.R);
+        load_synth_segment<K>(p, st, b, j, ia, ib, L0, L1);
+        walk_fast<K, MODE_SYNTH>(p, st, b, t, j, active, ia, L0, L1, 0, split);
+        load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);
+        walk_fast<K, MODE_SYNTH>(p, st, b, t, j, active, ib, L0, L1, split, p.R);
     } else {
         float lp[K];
 #pragma unroll
@@ -338,15 +401,10 @@ __global__ void __launch_bounds__(256) osc_frame_kernel(OscParams p)
             const int h = j + m * G;
             lp[m] = (h < p.H && b == 0 && p.live_in) ? p.live_in[h] : 0.0f;
         }
-        walk_exact<K, MODE>(p, st, lp, b, t, j, active, ia, ib, 0, split);
-        walk_exact<K, MODE>(p, st, lp, b, t, j, active, ib, ic, split, p.R);
-    }
-    if (MODE == MODE_TOTALS && active) {
-#pragma unroll
-        for (int m = 0; m < K; ++m) {
-            const int h = j + m * G;
-            if (h < p.H) p.ph0[((long)b * p.T + t) * p.H + h] = st.acc[m];
-        }
+        load_synth_segment<K>(p, st, b, j, ia, ib, L0, L1);
+        walk_exact<K, MODE_SYNTH>(p, st, lp, b, t, j, active, ia, L0, L1, 0, split);
+        load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);
+        walk_exact<K, MODE_SYNTH>(p, st, lp, b, t, j, active, ib, L0, L1, split, p.R);
     }
 }
 
@@ -386,23 +444,31 @@ hipError_t launch_frames(const OscParams &p, hipStream_t s)
     const long lanes = ((long)p.B * p.T) << p.logG;
     const unsigned grid = (unsigned)((lanes + 255) / 256);
     const bool live = p.live_in || p.live_out;
+    const size_t lds = (sizeof(double) * (size_t)(256 >> p.logG) + sizeof(float) * (size_t)((256 >> p.logG) + 2)) * p.H;
+    static bool lds_attr_set = false;  // superblocks of 256 short frames need more than the default 64 KiB
+    if (!lds_attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)osc_totals_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)osc_totals_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        lds_attr_set = true;
+    }
     int slot = ddsp_prof::begin(ddsp_prof::TOTALS, s);
     if (p.live_in) {
-        hipLaunchKernelGGL((osc_frame_kernel<K, MODE_TOTALS, VAR_EXACT>), dim3(grid), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((osc_totals_kernel<K, true>), dim3((unsigned)(p.B * p.NSB)), dim3(256), lds, s, p);
     } else {
-        hipLaunchKernelGGL((osc_frame_kernel<K, MODE_TOTALS, VAR_FAST>), dim3(grid), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((osc_totals_kernel<K, false>), dim3((unsigned)(p.B * p.NSB)), dim3(256), lds, s, p);
     }
     ddsp_prof::end(slot, s);
-    const int tiles = (p.H + 63) / 64;
     slot = ddsp_prof::begin(ddsp_prof::SCAN, s);
-    hipLaunchKernelGGL(osc_scan_kernel, dim3((unsigned)(p.B * tiles)), dim3(64 * kScanWaves), 0, s, p);
+    hipLaunchKernelGGL(osc_supscan_kernel, dim3((unsigned)(((long)p.B * p.H + 255) / 256)), dim3(256), 0, s, p);
     ddsp_prof::end(slot, s);
     slot = ddsp_prof::begin(ddsp_prof::SYNTH, s);
     if (!live && !p.force_exact)
-        hipLaunchKernelGGL((osc_frame_kernel<K, MODE_SYNTH, VAR_FAST>), dim3(grid), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST>), dim3(grid), dim3(256), 0, s, p);
     ddsp_prof::end(slot, s);
     // exits at once unless a wavefront of the FAST kernel raised redo_flag (or exactness is forced)
-    hipLaunchKernelGGL((osc_frame_kernel<K, MODE_SYNTH, VAR_EXACT>), dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((osc_synth_kernel<K, VAR_EXACT>), dim3(grid), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -421,11 +487,14 @@ extern "C" int ddsp_osc_set_tiling(int harmonics_per_lane)
     return 0;
 }
 
+// scratch layout: w | amp | loc | sup | flag; sup is sized for the smallest superblock (G = 64: 4 frames)
+size_t sup_elems(int B, int T, int H) { return (size_t)B * ((size_t)(T + 3) / 4) * H; }
+
 extern "C" size_t ddsp_osc_scratch_bytes(int B, int T, int H)
 {
     if (B <= 0 || T <= 0 || H <= 0) return 0;
     const size_t n = (size_t)B * T * H;
-    return 2 * align256(n * sizeof(float)) + align256(n * sizeof(double)) + 256;
+    return 2 * align256(n * sizeof(float)) + align256(n * sizeof(double)) + align256(sup_elems(B, T, H) * sizeof(double)) + 256;
 }
 
 extern "C" int ddsp_osc_forward(const float *f0, const float *c, const float *a, float *y, void *scratch,
@@ -445,23 +514,20 @@ extern "C" int ddsp_osc_forward(const float *f0, const float *c, const float *a,
     char *base = (char *)scratch;
     p.w = (float *)base;
     p.amp = (float *)(base + align256(n * sizeof(float)));
-    p.ph0 = (double *)(base + 2 * align256(n * sizeof(float)));
-    p.redo_flag = (int *)(base + 2 * align256(n * sizeof(float)) + align256(n * sizeof(double)));
+    p.loc = (double *)(base + 2 * align256(n * sizeof(float)));
+    p.sup = (double *)((char *)p.loc + align256(n * sizeof(double)));
+    p.redo_flag = (int *)((char *)p.sup + align256(sup_elems(B, T, H) * sizeof(double)));
     p.live_in = live_in; p.live_out = live_out; p.dbg_phi = dbg_phi;
     p.B = B; p.T = T; p.H = H; p.R = hop;
     p.logG = tl.logG;
+    p.NSB = (T + (256 >> tl.logG) - 1) / (256 >> tl.logG);
     p.force_exact = (dbg_phi != nullptr || live_in != nullptr || live_out != nullptr) ? 1 : 0;
     p.scale = (float)(1.0 / (double)hop);
     p.nyquist = (float)(sample_rate / 2);
     p.sr = (float)sample_rate;
 
     hipStream_t s = (hipStream_t)stream;
-    const long rows = (long)B * T;
-    const int slot = ddsp_prof::begin(ddsp_prof::PREP, s);
-    hipLaunchKernelGGL(osc_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
-    ddsp_prof::end(slot, s);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
+    hipError_t e = hipSuccess;
     switch (tl.K) {
 #define DDSP_CASE(KK) case KK: e = launch_frames<KK>(p, s); break;
         DDSP_CASE(4) DDSP_CASE(8) DDSP_CASE(12) DDSP_CASE(13) DDSP_CASE(15) DDSP_CASE(16) DDSP_CASE(20) DDSP_CASE(23) DDSP_CASE(25)
