@@ -42,7 +42,9 @@ class Conf:
 def cpu_baseline(shape, seconds_target=12.0):
     """Reference CPU path (torch-op restatement) on a bounded sample: B=8 rows of the same workload."""
     from oracle import torch_restatement as tr
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU a share of 16 host cores (os.cpu_count() reports the whole machine)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = int(os.environ.get("DDSP_CPU_THREADS", min(avail, 16)))
     torch.set_num_threads(cores)
     b = 8
     ctl = syn.make_controls(shape, 1004, "all_live", batch=b)

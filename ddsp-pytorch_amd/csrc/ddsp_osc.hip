@@ -411,9 +411,19 @@ __global__ void __launch_bounds__(256) osc_synth_kernel(OscParams p)
 // ---- host side ---------------------------------------------------------------------------------
 struct Tiling { int K, logG; };
 
-// Harmonics per lane K (compile-time, register resident) and lanes per frame G = 2^logG with
-// G*K >= H, minimising padded (idle) harmonic slots; ties go to the larger K.
+// Harmonics per lane K (compile-time, register resident) and lanes per frame G = 2^logG with G*K >= H.
+// Cost model (measured on MI355X): padded harmonic slots are pure waste; the per-sample work
+// shared by a lane's harmonics (weights, cross-lane sum, store) is amortised over K; K >= 20 leaves only two
+// wavefronts per SIMD (>= 200 VGPRs), which costs about 10 %.
 const int kKs[] = {4, 8, 12, 13, 15, 16, 20, 23, 25};
+
+double tiling_cost(int H, int K, int logG)
+{
+    const double waste = (double)((1 << logG) * K) / (double)H;
+    const double shared = 1.0 + (0.5 + 0.08 * logG) / (double)K;
+    const double occupancy = K >= 20 ? 1.10 : (K >= 15 ? 1.03 : 1.0);
+    return waste * shared * occupancy;
+}
 
 int g_forced_k = 0;  // ddsp_osc_set_tiling: 0 = automatic
 
@@ -427,9 +437,9 @@ bool pick_tiling(int H, Tiling *out)
         int logG = 0;
         while ((1 << logG) < lanes) ++logG;
         if (logG > 6) continue;
-        const double waste = (double)((1 << logG) * K) / (double)H;
-        if (waste <= best + 1e-12) {
-            best = waste;
+        const double cost = tiling_cost(H, K, logG);
+        if (cost < best) {
+            best = cost;
             out->K = K;
             out->logG = logG;
             found = true;
