@@ -7,7 +7,8 @@ kernels (gfx950) behind the C ABI declared in `include/ddsp_hip.h`.
 """
 from . import synthetic  # noqa: F401
 from . import _lib  # noqa: F401
-from .harmonic_oscillator import OscillatorBank, osc_forward  # noqa: F401
-from .filtered_noise import FilteredNoise, noise_forward  # noqa: F401
+from .harmonic_oscillator import OscillatorBank, osc_forward, osc_backward  # noqa: F401
+from .filtered_noise import FilteredNoise, noise_forward, noise_backward  # noqa: F401
 
-__all__ = ["OscillatorBank", "FilteredNoise", "osc_forward", "noise_forward", "synthetic"]
+__all__ = ["OscillatorBank", "FilteredNoise", "osc_forward", "osc_backward", "noise_forward", "noise_backward",
+           "synthetic"]

@@ -51,6 +51,12 @@ def lib():
     L.ddsp_noise_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, u64, u64, i32, vp]
     L.ddsp_osc_set_tiling.restype = i32
     L.ddsp_osc_set_tiling.argtypes = [i32]
+    L.ddsp_osc_backward_scratch_bytes.restype = ctypes.c_size_t
+    L.ddsp_osc_backward_scratch_bytes.argtypes = [i32, i32, i32]
+    L.ddsp_osc_backward.restype = i32
+    L.ddsp_osc_backward.argtypes = [vp] * 8 + [i32] * 5 + [vp]
+    L.ddsp_noise_backward.restype = i32
+    L.ddsp_noise_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, u64, u64, vp]
     L.ddsp_noise_set_generic.restype = i32
     L.ddsp_noise_set_generic.argtypes = [i32]
     L.ddsp_profile_enable.restype = i32
@@ -64,6 +70,7 @@ def lib():
 
 
 EXPORTS = ("ddsp_hip_abi_version", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_noise_forward",
+           "ddsp_osc_backward_scratch_bytes", "ddsp_osc_backward", "ddsp_noise_backward",
            "ddsp_osc_set_tiling", "ddsp_noise_set_generic", "ddsp_profile_enable", "ddsp_profile_read")
 
 KERNEL_NAMES = {0: "osc_prep", 1: "osc_frame_totals", 2: "osc_scan", 3: "osc_frame_synth", 4: "noise_frame"}

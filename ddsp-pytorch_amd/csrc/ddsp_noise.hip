@@ -282,6 +282,217 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
     }
 }
 
+// =====================================================================================================
+// Backward w.r.t. the filter magnitudes H (autograd of filtered_noise.py:40-53; the noise draw is a constant).
+//   y[n] = sum_{m<=n} x[m] kern[n-m]                 =>  d/dkern[j] = sum_{d=0}^{R-1-j} x[d] g[j+d]
+//   kern[j] = z[(src+S/2)%S] * hann[src], src <-> j  =>  d/dz folded onto n in [0,S/2]:  Gs[n]
+//   z[n] = (H0 + (-1)^n H_{S/2} + 2 sum_k H_k cos(2 pi k n / S)) / S
+//                                                    =>  d/dH_k = c_k/S (Gs[0] + (-1)^k Gs[S/2] + sum_{n=1}^{S/2-1} Gs[n] cos(2 pi k n / S)),
+//                                                        c_k = 1 for k in {0, S/2}, 2 otherwise
+// =====================================================================================================
+struct NoiseBwdParams {
+    const float *g;      // [B,T*R] upstream gradient
+    const float *u;      // [B,T,R] the forward's uniform draw (nullable -> Philox from seed/offset, as the forward)
+    float *gH;           // [B,T,F]
+    int B, T, F, R, S;
+    uint64_t seed, offset;
+};
+
+__device__ __forceinline__ float noise_sample(const float *u, long frame, int m, int R, uint64_t seed, uint64_t offset)
+{
+    if (u) return u[frame * R + m] * 2.0f - 1.0f;
+    const int quads = (R + 3) >> 2;
+    const uint64_t ctr = offset + (uint64_t)frame * (uint64_t)quads + (uint64_t)(m >> 2);
+    uint32_t r[4];
+    philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    return (float)(r[m & 3] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+}
+
+// Generic backward: one frame per workgroup, any hop / F.
+__global__ void __launch_bounds__(256) noise_bwd_frame_kernel(NoiseBwdParams p)
+{
+    extern __shared__ float smem[];
+    const int S = p.S, R = p.R, F = p.F, half = S >> 1;
+    float *ct = smem;          // [S]
+    float *x = ct + S;         // [R]
+    float *g = x + R;          // [R]
+    float *Gs = g + R;         // [half + 1]
+    const long frame = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int m = tid; m < S; m += 256) ct[m] = cospif((float)(2 * m) / (float)S);
+    for (int m = tid; m < R; m += 256) {
+        x[m] = noise_sample(p.u, frame, m, R, p.seed, p.offset);
+        g[m] = p.g[frame * R + m];
+    }
+    for (int n = tid; n <= half; n += 256) Gs[n] = 0.0f;
+    __syncthreads();
+    const int taps = min(S, R);
+    for (int src = tid; src < taps; src += 256) {
+        int j = (src - half) % R;
+        if (j < 0) j += R;
+        float acc = 0.0f;
+        for (int d = 0; d + j < R; ++d) acc = __fmaf_rn(x[d], g[j + d], acc);
+        const int nf = (src + half) % S;
+        const int nn = nf <= half ? nf : S - nf;
+        atomicAdd(&Gs[nn], acc * (0.5f - 0.5f * ct[src]));   // at most two addends per bin: order-independent
+    }
+    __syncthreads();
+    const float invS = 1.0f / (float)S;
+    for (int k = tid; k < F; k += 256) {
+        float acc = 0.0f;
+        int idx = 0;
+        for (int n = 1; n < half; ++n) {
+            idx += k;
+            if (idx >= S) idx -= S;
+            acc = __fmaf_rn(Gs[n], ct[idx], acc);
+        }
+        const float edge = Gs[0] + ((k & 1) ? -Gs[half] : Gs[half]);
+        const float ck = (k == 0 || k == half) ? 1.0f : 2.0f;
+        p.gH[frame * F + k] = ck * invS * (edge + acc);
+    }
+}
+
+// Batched backward: 64 frames per workgroup, lane = frame (mirror of noise_batched_kernel).
+__global__ void __launch_bounds__(kNT) noise_bwd_batched_kernel(NoiseBwdParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int S = p.S, R = p.R, F = p.F, half = S >> 1;
+    const int XS = R + 4, GS = R + 12;
+    float *ct = smem;                                   // [S] rounded up to a multiple of 4
+    float *xs = ct + ((S + 3) & ~3);                    // [64][XS]
+    float *gs = xs + kFB * XS;                          // [64][GS]  (7+ zeros after the R samples)
+    float *GsT = gs + kFB * GS;                         // [(half+1)][kHS]  folded d/dz, transposed
+    const int tid = threadIdx.x;
+    const long frame0 = (long)blockIdx.x * kFB;
+    const long nframes = (long)p.B * p.T;
+    const int nf = (int)min((long)kFB, nframes - frame0);
+
+    for (int m = tid; m < S; m += kNT) ct[m] = cospif((float)(2 * m) / (float)S);
+    for (int e = tid; e < (half + 1) * kHS; e += kNT) GsT[e] = 0.0f;
+    for (int e = tid; e < kFB * GS; e += kNT) {
+        const int f = e / GS, m = e - f * GS;
+        gs[e] = (f < nf && m < R) ? p.g[(frame0 + f) * R + m] : 0.0f;
+    }
+    if (p.u) {
+        for (int e = tid; e < kFB * R; e += kNT) {
+            const int f = e / R, m = e - f * R;
+            xs[f * XS + m] = (f < nf) ? p.u[(frame0 + f) * R + m] * 2.0f - 1.0f : 0.0f;
+        }
+    } else {
+        const int quads = R >> 2;
+        for (int e = tid; e < kFB * quads; e += kNT) {
+            const int f = e / quads, q = e - f * quads;
+            const uint64_t ctr = p.offset + (uint64_t)(frame0 + f) * (uint64_t)quads + (uint64_t)q;
+            uint32_t r[4];
+            philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r);
+            float4 v;
+            v.x = (float)(r[0] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+            v.y = (float)(r[1] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+            v.z = (float)(r[2] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+            v.w = (float)(r[3] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+            *reinterpret_cast<float4 *>(&xs[f * XS + 4 * q]) = v;
+        }
+    }
+    __syncthreads();
+
+    // correlation d/dkern[j] = sum_d x[d] g[j+d], 8 taps x 8 lags per step, chunk c paired with C-1-c
+    const int lane = tid & 63, wv = tid >> 6;
+    const int C = R >> 3;
+    const int taps = min(S, R);
+    const float *xrow = xs + lane * XS;
+    const float *grow = gs + lane * GS;
+    for (int pr = wv; 2 * pr < C; pr += kNT / 64) {
+#pragma unroll 1
+        for (int side = 0; side < 2; ++side) {
+            const int c = side ? C - 1 - pr : pr;
+            if (side && c == pr) break;
+            const int j0 = c << 3;
+            float acc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = 0.0f;
+            for (int d = 0; d + j0 < R; d += 8) {
+                const float4 xa = *reinterpret_cast<const float4 *>(xrow + d);
+                const float4 xb = *reinterpret_cast<const float4 *>(xrow + d + 4);
+                const float4 ga = *reinterpret_cast<const float4 *>(grow + j0 + d);
+                const float4 gb = *reinterpret_cast<const float4 *>(grow + j0 + d + 4);
+                const float4 gc = *reinterpret_cast<const float4 *>(grow + j0 + d + 8);
+                const float4 gd = *reinterpret_cast<const float4 *>(grow + j0 + d + 12);
+                asm volatile("" ::"v"(gd.w));  // keep the window as 4 x ds_read_b128
+                const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                const float gw[16] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w, gc.x, gc.y, gc.z, gc.w, gd.x, gd.y, gd.z, gd.w};
+#pragma unroll
+                for (int v = 0; v < 8; ++v)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc[u] = __fmaf_rn(xv[v], gw[u + v], acc[u]);
+            }
+            // window, fold onto n in [0, S/2] (two taps can meet in one bin: a 2-term sum is order-independent)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                // j = (src - half) mod R with src in [0, taps)  <=>  src = (j + half) mod R when that is < taps
+                int src = (j + half) % R;
+                if (src < taps && ((src - half) % R + R) % R == j) {
+                    const int nfull = (src + half) % S;
+                    const int nn = nfull <= half ? nfull : S - nfull;
+                    atomicAdd(&GsT[nn * kHS + lane], acc[u] * (0.5f - 0.5f * ct[src]));
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // d/dH_k: cosine sums over n, k = 1..S/4 paired with S/2-k, 4 frames per thread
+    const float invS = 1.0f / (float)S;
+    {   // k = 0 and k = S/2: plain and alternating sums, 8 lanes per frame
+        const int f = tid >> 3, part = tid & 7;
+        float e = 0.0f, o = 0.0f;
+        for (int n = 1 + part; n < half; n += 8) {
+            const float v = GsT[n * kHS + f];
+            if (n & 1) o += v; else e += v;
+        }
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) { e += __shfl_xor(e, m); o += __shfl_xor(o, m); }
+        if (part == 0 && f < nf) {
+            const float v0 = GsT[f], vh = GsT[half * kHS + f];
+            p.gH[(frame0 + f) * F + 0] = invS * (v0 + vh + e + o);
+            if (half > 0) p.gH[(frame0 + f) * F + half] = invS * (v0 + ((half & 1) ? -vh : vh) + e - o);
+        }
+    }
+    const int nmain = half / 2;
+    for (int item = tid; item < nmain * (kFB / 4); item += kNT) {
+        const int fq = item / nmain, k = 1 + item - fq * nmain;
+        float ev[4] = {0, 0, 0, 0}, ov[4] = {0, 0, 0, 0};
+        int idx = 0;
+        for (int n = 1; n < half; ++n) {
+            idx += k;
+            if (idx >= S) idx -= S;
+            const float cc = ct[idx];
+            const float4 v = *reinterpret_cast<const float4 *>(&GsT[n * kHS + 4 * fq]);
+            if (n & 1) { ov[0] = __fmaf_rn(v.x, cc, ov[0]); ov[1] = __fmaf_rn(v.y, cc, ov[1]); ov[2] = __fmaf_rn(v.z, cc, ov[2]); ov[3] = __fmaf_rn(v.w, cc, ov[3]); }
+            else       { ev[0] = __fmaf_rn(v.x, cc, ev[0]); ev[1] = __fmaf_rn(v.y, cc, ev[1]); ev[2] = __fmaf_rn(v.z, cc, ev[2]); ev[3] = __fmaf_rn(v.w, cc, ev[3]); }
+        }
+        const float4 v0 = *reinterpret_cast<const float4 *>(&GsT[4 * fq]);
+        const float4 vh = *reinterpret_cast<const float4 *>(&GsT[half * kHS + 4 * fq]);
+        const float v0v[4] = {v0.x, v0.y, v0.z, v0.w}, vhv[4] = {vh.x, vh.y, vh.z, vh.w};
+        const int k2 = half - k;
+        const float sg1 = (k & 1) ? -1.0f : 1.0f, sg2 = (k2 & 1) ? -1.0f : 1.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f = 4 * fq + q;
+            if (f < nf) {
+                p.gH[(frame0 + f) * F + k] = 2.0f * invS * (v0v[q] + sg1 * vhv[q] + ev[q] + ov[q]);
+                if (k2 != k) p.gH[(frame0 + f) * F + k2] = 2.0f * invS * (v0v[q] + sg2 * vhv[q] + ev[q] - ov[q]);
+            }
+        }
+    }
+}
+
+size_t bwd_batched_lds_bytes(int F, int R)
+{
+    const int S = 2 * (F - 1);
+    return sizeof(float) * (((S + 3) & ~3) + (size_t)kFB * (R + 4) + (size_t)kFB * (R + 12) + (size_t)(S / 2 + 1) * kHS);
+}
+
 size_t batched_lds_bytes(int F, int R)
 {
     const int S = 2 * (F - 1);
@@ -329,4 +540,33 @@ extern "C" int ddsp_noise_set_generic(int on)
 {
     g_force_generic = on;
     return 0;
+}
+
+extern "C" int ddsp_noise_backward(const float *grad_y, const float *uniform, float *grad_H, int B, int T, int F, int hop,
+                                   uint64_t seed, uint64_t offset, void *stream)
+{
+    if (B == 0) return 0;
+    if (!grad_y || !grad_H || B < 0 || T <= 0 || F < 2 || hop <= 0) return DDSP_EINVAL;
+    if ((long)B * T >= (1L << 31)) return DDSP_ERANGE;
+    NoiseBwdParams p;
+    p.g = grad_y; p.u = uniform; p.gH = grad_H;
+    p.B = B; p.T = T; p.F = F; p.R = hop; p.S = 2 * (F - 1);
+    p.seed = seed; p.offset = offset;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t blds = bwd_batched_lds_bytes(F, hop);
+    if (!(g_force_generic & 1) && hop % 8 == 0 && blds <= 160 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void *)noise_bwd_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        const long blocks = ((long)B * T + kFB - 1) / kFB;
+        hipLaunchKernelGGL(noise_bwd_batched_kernel, dim3((unsigned)blocks), dim3(kNT), blds, s, p);
+        return (int)hipGetLastError();
+    }
+    const size_t lds = sizeof(float) * ((size_t)p.S + 2 * (size_t)hop + p.S / 2 + 1);
+    if (lds > 64 * 1024) return DDSP_ERANGE;
+    hipLaunchKernelGGL(noise_bwd_frame_kernel, dim3((unsigned)((long)B * T)), dim3(256), lds, s, p);
+    return (int)hipGetLastError();
 }

@@ -1,0 +1,153 @@
+// Shared device helpers and host-side parameter block of the oscillator kernels
+// (ddsp_osc.hip: forward, ddsp_osc_bwd.hip: backward).  See ddsp_osc.hip for the design notes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ddsp_osc {
+
+
+constexpr float kTwoPi32 = 6.2831854820251465f;     // fl32(2*pi): the modulus the reference uses (:34,:42)
+constexpr float kInvTwoPi32 = 0.15915493667125702f; // fl32(1/fl32(2*pi))
+constexpr float kRevPerRad = 0.15915494309189535f;  // 1/(2*pi) for v_sin_f32 (argument in revolutions)
+constexpr float kFastPhaseLimit = 1.0e7f;           // fast modulo is exact while P/2pi32 < 2^21
+constexpr float kRoundMagic = 12582912.0f;          // 1.5*2^23: (x + magic) - magic = rint(x) for |x| < 2^22
+
+struct OscParams {
+    const float *f0, *c, *a;
+    float *y;
+    float *w, *amp;   // scratch [B,T,H]: written by the totals kernel (row t), read by the synth kernels
+    double *loc;      // scratch [B,T,H]: exclusive prefix of the frame totals inside the frame's superblock
+    double *sup;      // scratch [B,NSB,H]: superblock totals, then (in place) their exclusive scan along t
+    int *redo_flag;   // scratch: set by the FAST synth kernel when a wavefront needs the EXACT one
+    const float *live_in;
+    float *live_out;
+    float *dbg_phi;
+    const float *grad_y;  // backward: [B,N]
+    float *part_c;        // backward scratch [B,T,3,H]: partial d/d(amp) aimed at rows t-1, t, t+1
+    float *part_a;        // backward scratch [B,T,3]:   partial d/d(a)
+    float *grad_c, *grad_a;
+    int B, T, H, R;
+    int K;            // harmonics per lane (template instance to launch)
+    int logG;         // lanes per frame group
+    int NSB;          // superblocks per batch row = ceil(T / (256 >> logG))
+    int force_exact;
+    float scale;      // fl32(1/R): F.interpolate's source-index scale
+    float nyquist;    // float(sample_rate // 2)
+    float sr;         // float(sample_rate)
+};
+
+// ---- cross-lane helpers -------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum over the G = 2^logG lanes of a group (groups are G-aligned); every lane of the group gets the total
+// (each step is a symmetric exchange).
+__device__ __forceinline__ float group_sum(float v, int logG)
+{
+    if (logG >= 1) v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    if (logG >= 2) v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    if (logG >= 3) v += dpp_mov<0x141>(v);  // row_half_mirror
+    if (logG >= 4) v += dpp_mov<0x140>(v);  // row_mirror
+    if (logG >= 5) v += __shfl_xor(v, 16);
+    if (logG >= 6) v += __shfl_xor(v, 32);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// torch CPU `%=` on floats (aten remainder): fmod, then shifted into the divisor's sign.
+__device__ __forceinline__ float remainder_two_pi(float p)
+{
+    float r = fmodf(p, kTwoPi32);
+    if (r != 0.0f && r < 0.0f) r += kTwoPi32;
+    return r;
+}
+
+enum { MODE_TOTALS = 0, MODE_SYNTH = 1 };
+// FAST: production path.  EXACT: bit-exact modulo (libm fmodf), live state and debug outputs; it also
+// repairs the wavefronts the FAST synth kernel declined (phases outside the fast modulo's exact range).
+enum { VAR_FAST = 0, VAR_EXACT = 1 };
+
+template <int K>
+struct FrameState {
+    double acc[K];
+    float x0[K], x1[K];  // frame-rate increments at the bracketing frames i0, i1
+    float a0[K], da[K];  // amplitude at i0 and (amp[i1] - amp[i0])   (synth only)
+};
+
+// First sample index n in [0,R) of frame t whose interpolation source index is >= t, i.e. where
+// F.interpolate switches from frames (t-1,t) to (t,t+1).  Evaluated with the reference's own fp32
+// expression so that it is right for every hop (R/2 for even hops in exact arithmetic).
+__device__ __forceinline__ int split_index(int t, int R, float scale)
+{
+    int m = R >> 1;
+    if (t == 0) return m;  // both halves clamp to frame 0: any split gives identical results
+    const float tf = (float)t;
+    const int base = t * R;
+    while (m > 0 && __fmaf_rn(scale, (float)(base + m - 1) + 0.5f, -0.5f) >= tf) --m;
+    while (m < R && __fmaf_rn(scale, (float)(base + m) + 0.5f, -0.5f) < tf) ++m;
+    return m;
+}
+
+// F.interpolate(linear, align_corners=False) weights of output sample i against source frame i0: App. A item 4
+__device__ __forceinline__ void upsample_weights(float scale, int i, float i0f, float &w0, float &w1)
+{
+    float src = __fmaf_rn(scale, (float)i + 0.5f, -0.5f);
+    src = fmaxf(src, 0.0f);
+    w1 = fminf(fmaxf(src - i0f, 0.0f), 1.0f);
+    w0 = 1.0f - w1;
+}
+
+// rad/sample of harmonic h (0-based) at fundamental f: two roundings and a true division (:26-35, App. A item 3)
+__device__ __forceinline__ float frame_increment(int h, float f, float sr)
+{
+    const float hz = (float)(h + 1) * f;
+    const float rad = hz * kTwoPi32;
+    return rad / sr;
+}
+
+template <int K>
+__device__ __forceinline__ void load_synth_segment(const OscParams &p, FrameState<K> &st, int b, int j, int i0, int i1,
+                                                   float &L0, float &L1)
+{
+    const int G = 1 << p.logG;
+    const long rowbase = (long)b * p.T;
+    const float *w0row = p.w + (rowbase + i0) * p.H;
+    const float *w1row = p.w + (rowbase + i1) * p.H;
+    const float *a0row = p.amp + (rowbase + i0) * p.H;
+    const float *a1row = p.amp + (rowbase + i1) * p.H;
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+        const int h = j + m * G;
+        const bool ok = h < p.H;
+        st.x0[m] = ok ? w0row[h] : 0.0f;
+        st.x1[m] = ok ? w1row[h] : 0.0f;
+        const float u0 = ok ? a0row[h] : 0.0f;
+        const float u1 = ok ? a1row[h] : 0.0f;
+        st.a0[m] = u0;
+        st.da[m] = u1 - u0;
+    }
+    L0 = p.a[rowbase + i0];
+    L1 = p.a[rowbase + i1];
+}
+
+
+// ---- host side (defined in ddsp_osc.hip) ---------------------------------------------------------------
+struct Tiling { int K, logG; };
+bool pick_tiling(int H, Tiling *out);
+inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+// scratch layout: w | amp | loc | sup | flag; sup is sized for the smallest superblock (G = 64: 4 frames)
+inline size_t sup_elems(int B, int T, int H) { return (size_t)B * ((size_t)(T + 3) / 4) * H; }
+// Fills the shape-derived fields and carves the scratch buffer; returns false if no tiling exists for H.
+bool setup_params(OscParams &p, void *scratch, int B, int T, int H, int hop, int sample_rate);
+
+}  // namespace ddsp_osc

@@ -40,6 +40,41 @@ def noise_forward(Hmag, hop: int, uniform=None, seed: int = 0, offset: int = 0, 
     return out
 
 
+def noise_backward(grad_y, hop: int, n_filters: int, uniform=None, seed: int = 0, offset: int = 0):
+    """Raw launcher of ddsp_noise_backward: grad_y [B,T*hop] -> grad_H [B,T,F] for the same draw as the forward."""
+    grad_y = grad_y.detach().contiguous().float()
+    B = grad_y.shape[0]
+    T = grad_y.shape[1] // hop
+    grad_h = torch.empty((B, T, n_filters), device=grad_y.device, dtype=torch.float32)
+    if B == 0:
+        return grad_h
+    with torch.cuda.device(grad_y.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = _lib.lib().ddsp_noise_backward(grad_y.data_ptr(), None if uniform is None else uniform.data_ptr(),
+                                            grad_h.data_ptr(), B, T, n_filters, hop, seed, offset, stream)
+    _lib.check(rc, "ddsp_noise_backward")
+    return grad_h
+
+
+class _NoiseFunction(torch.autograd.Function):
+    """Differentiable w.r.t. H; the noise draw is a constant of the graph (filtered_noise.py:44-48)."""
+
+    @staticmethod
+    def forward(ctx, Hmag, uniform, hop, seed, offset):
+        if uniform is not None:
+            uniform = uniform.detach().to(device=Hmag.device, dtype=torch.float32).contiguous()
+        y = noise_forward(Hmag, hop, uniform=uniform, seed=seed, offset=offset)
+        ctx.save_for_backward(uniform)
+        ctx.meta = (hop, Hmag.shape[-1], seed, offset)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        (uniform,) = ctx.saved_tensors
+        hop, nf, seed, offset = ctx.meta
+        return noise_backward(grad_y, hop, nf, uniform=uniform, seed=seed, offset=offset), None, None, None, None
+
+
 class FilteredNoise(nn.Module):
     def __init__(self, conf, rng: str = 'host', seed: int = 0):
         super().__init__()
@@ -60,4 +95,8 @@ class FilteredNoise(nn.Module):
             quads = (self.block_size + 3) // 4
             offset = self._calls * B * T * quads
             self._calls += 1
+        if torch.is_grad_enabled() and param.requires_grad:
+            if not param.is_cuda:
+                raise _lib.DdspHipError("FilteredNoise runs on the GPU only (no CPU fallback): move the controls to cuda")
+            return _NoiseFunction.apply(param, noise, self.block_size, self.seed, offset)
         return noise_forward(param, self.block_size, uniform=noise, seed=self.seed, offset=offset)

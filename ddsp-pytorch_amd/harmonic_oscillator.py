@@ -26,8 +26,9 @@ def _check_inputs(f0, c, a):
         raise _lib.DdspHipError("OscillatorBank runs on the GPU only (no CPU fallback): move the controls to cuda")
 
 
-def osc_forward(f0, c, a, hop: int, sample_rate: int, live_in=None, want_live_out=False, debug_phases=False):
-    """Raw launcher over the C ABI (include/ddsp_hip.h: ddsp_osc_forward). Returns (y, live_out, phi)."""
+def osc_forward(f0, c, a, hop: int, sample_rate: int, live_in=None, want_live_out=False, debug_phases=False,
+                return_scratch=False):
+    """Raw launcher over the C ABI (include/ddsp_hip.h: ddsp_osc_forward). Returns (y, live_out, phi[, scratch])."""
     _check_inputs(f0, c, a)
     f0 = f0.detach().contiguous().float()
     c = c.detach().contiguous().float()
@@ -36,7 +37,7 @@ def osc_forward(f0, c, a, hop: int, sample_rate: int, live_in=None, want_live_ou
     L = _lib.lib()
     y = torch.empty((B, T * hop), device=c.device, dtype=torch.float32)
     if B == 0:
-        return y, None, None
+        return (y, None, None, None) if return_scratch else (y, None, None)
     scratch = torch.empty(L.ddsp_osc_scratch_bytes(B, T, H), device=c.device, dtype=torch.uint8)
     live_out = torch.empty(H, device=c.device, dtype=torch.float32) if want_live_out else None
     phi = torch.empty((B, T * hop, H), device=c.device, dtype=torch.float32) if debug_phases else None
@@ -47,7 +48,45 @@ def osc_forward(f0, c, a, hop: int, sample_rate: int, live_in=None, want_live_ou
         rc = L.ddsp_osc_forward(f0.data_ptr(), c.data_ptr(), a.data_ptr(), y.data_ptr(), scratch.data_ptr(),
                                 _dev_ptr(live_in), _dev_ptr(live_out), _dev_ptr(phi), B, T, H, hop, sample_rate, stream)
     _lib.check(rc, "ddsp_osc_forward")
-    return y, live_out, phi
+    return (y, live_out, phi, scratch) if return_scratch else (y, live_out, phi)
+
+
+def osc_backward(grad_y, f0, c, a, scratch, hop: int, sample_rate: int):
+    """Raw launcher of ddsp_osc_backward: -> (grad_c [B,T,H], grad_a [B,T,1]); `scratch` comes from the forward."""
+    B, T, H = c.shape
+    L = _lib.lib()
+    grad_y = grad_y.detach().contiguous().float()
+    grad_c = torch.empty_like(c)
+    grad_a = torch.empty_like(a)
+    if B == 0:
+        return grad_c, grad_a
+    bwd = torch.empty(L.ddsp_osc_backward_scratch_bytes(B, T, H), device=c.device, dtype=torch.uint8)
+    with torch.cuda.device(c.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = L.ddsp_osc_backward(grad_y.data_ptr(), f0.data_ptr(), c.data_ptr(), a.data_ptr(), scratch.data_ptr(),
+                                 bwd.data_ptr(), grad_c.data_ptr(), grad_a.data_ptr(), B, T, H, hop, sample_rate, stream)
+    _lib.check(rc, "ddsp_osc_backward")
+    return grad_c, grad_a
+
+
+class _OscillatorFunction(torch.autograd.Function):
+    """Differentiable w.r.t. c and a (train/train.py:33-34); f0 carries no gradient (decoder.py:105)."""
+
+    @staticmethod
+    def forward(ctx, f0, c, a, hop, sample_rate):
+        f0 = f0.detach().contiguous().float()
+        c = c.detach().contiguous().float()
+        a = a.detach().contiguous().float()
+        y, _, _, scratch = osc_forward(f0, c, a, hop, sample_rate, return_scratch=True)
+        ctx.save_for_backward(f0, c, a, scratch)
+        ctx.hop, ctx.sample_rate = hop, sample_rate
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        f0, c, a, scratch = ctx.saved_tensors
+        grad_c, grad_a = osc_backward(grad_y, f0, c, a, scratch, ctx.hop, ctx.sample_rate)
+        return None, grad_c, grad_a, None, None
 
 
 class OscillatorBank(nn.Module):
@@ -62,7 +101,11 @@ class OscillatorBank(nn.Module):
         self.last_phases = nn.Parameter(torch.zeros_like(self.harmonics), requires_grad=False)
 
     def forward(self, x):
-        y, _, _ = osc_forward(x['f0'], x['c'], x['a'], self.hop_size, self.sample_rate)
+        f0, c, a = x['f0'], x['c'], x['a']
+        if torch.is_grad_enabled() and (c.requires_grad or a.requires_grad):
+            _check_inputs(f0, c, a)
+            return _OscillatorFunction.apply(f0, c, a, self.hop_size, self.sample_rate)
+        y, _, _ = osc_forward(f0, c, a, self.hop_size, self.sample_rate)
         return y
 
     def live(self, x):

@@ -72,6 +72,24 @@ int ddsp_noise_forward(const float *Hmag, const float *uniform, float *y,
                        int accumulate, void *stream);
 
 /*
+ * Backward of ddsp_osc_forward w.r.t. c and a (autograd of harmonic_oscillator.py:24-62; f0 carries no gradient,
+ * decoder.py:105).  `fwd_scratch` is the scratch buffer the matching ddsp_osc_forward call filled (same B,T,H,hop,
+ * sample_rate, same tiling); `bwd_scratch` >= ddsp_osc_backward_scratch_bytes(B,T,H).
+ *   grad_y [B,T*hop] -> grad_c [B,T,H], grad_a [B,T,1]
+ */
+size_t ddsp_osc_backward_scratch_bytes(int B, int T, int H);
+int ddsp_osc_backward(const float *grad_y, const float *f0, const float *c, const float *a, const void *fwd_scratch,
+                      void *bwd_scratch, float *grad_c, float *grad_a, int B, int T, int H, int hop, int sample_rate,
+                      void *stream);
+
+/*
+ * Backward of ddsp_noise_forward w.r.t. Hmag (autograd of filtered_noise.py:40-53; the noise draw is a constant).
+ * `uniform`/`seed`/`offset` must be the forward call's.   grad_y [B,T*hop] -> grad_H [B,T,F]
+ */
+int ddsp_noise_backward(const float *grad_y, const float *uniform, float *grad_H, int B, int T, int F, int hop,
+                        uint64_t seed, uint64_t offset, void *stream);
+
+/*
  * Tuning hook (benchmarks only): force the number of harmonics each lane keeps in registers
  * (one of 4,8,12,13,15,16,20,23,25); 0 restores the automatic choice.  Process-global, not
  * thread-safe; results are identical for every setting.
