@@ -64,6 +64,57 @@ def cpu_baseline(shape, seconds_target=12.0):
                       f"restatement of harmonic_oscillator.py+filtered_noise.py, {el:.1f} s"}
 
 
+def train_mode(args, rank, world, dist):
+    """BASELINE.json configs[4]: synth + MSS loss + Adam, batch 32 per GPU, one flat gradient all-reduce per step."""
+    class TrainConf:
+        n_harmonics, n_noise_filters, sample_rate, hop_length = 100, 65, 16000, 128
+        decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 512, 3, 512, 1
+
+    b, frames = args.batch or 32, 500
+    torch.manual_seed(0)                                     # identical replicas on every rank
+    model = ddsp.Decoder(TrainConf, noise_rng="device", seed=rank).cuda()
+    loss_fn = ddsp.MSSLoss().cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    rng = np.random.default_rng(2000 + rank)
+    batch = {"normalized_cents": torch.from_numpy(rng.uniform(0, 1, (b, frames, 1)).astype(np.float32)).cuda(),
+             "loudness": torch.from_numpy(rng.uniform(-1, 1, (b, frames, 1)).astype(np.float32)).cuda(),
+             "f0": torch.from_numpy(syn.musical_f0(rng, b, frames)).cuda(),
+             "audio": torch.from_numpy((0.1 * rng.standard_normal((b, frames * 128))).astype(np.float32)).cuda()}
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    nbytes = 0
+    for _ in range(args.warmup):
+        _, nbytes = ddsp.train_step(model, loss_fn, opt, batch)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, nbytes = ddsp.train_step(model, loss_fn, opt, batch)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "train-step audio samples/sec (BASELINE.json configs[4]; secondary figure)",
+            "value": world * b * frames * 128 * args.steps / elapsed, "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"decoder (4.84 M params) + HIP synth + reverb + MSS loss (6 scales) + Adam, batch {b}/GPU, "
+                                   f"16 kHz, 100 harmonics, 65 noise bands, 4 s", "parallelism": f"dp{world}, one flat all-reduce",
+                       "allreduce_bytes": nbytes},
+            "final_loss": float(loss)}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +124,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="rows per GPU (default: the metric's 512)")
     ap.add_argument("--tiling", type=int, default=0, help="force harmonics per lane (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="synth", choices=["synth", "train"],
+                    help="synth: the headline hot path; train: BASELINE.json configs[4] (decoder + MSS loss + Adam, "
+                         "batch 32/GPU, flat RCCL gradient all-reduce) -- a secondary figure, not the metric")
     ap.add_argument("--noise", default="device", choices=["device", "resident"],
                     help="uniform draw: in-kernel Philox, or a [B,T,hop] tensor already resident in HBM")
     args = ap.parse_args()
@@ -90,6 +144,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
+    if args.mode == "train":
+        return train_mode(args, rank, world, dist)
     shape = syn.CFG4_PER_GPU
     if args.batch:
         shape = syn.SynthShape(shape.name, args.batch, shape.sample_rate, shape.hop, shape.frames, shape.n_harmonics,

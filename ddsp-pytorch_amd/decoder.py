@@ -1,0 +1,89 @@
+"""Callers of the hot path: the control network and the `Decoder`
+wiring of model/autoencoder/decoder.py:41-147, restated with stock torch.nn layers (rocBLAS / MIOpen do
+the dense work; nothing hand-written here) around the HIP synth modules of this package.
+
+Sub-module and parameter names follow the reference so that its checkpoints load with strict=True
+(`rt/utils.py:7-24` strips the `model.` prefix, `rt/synth.py:17` loads into `zak.decoder`):
+  controller.mlp_f0 / mlp_loudness / gru / mlp_gru / dense_harmonic / dense_loudness / dense_filter,
+  harmonics.{harmonics,last_phases}, reverb.{noise,decay,wet,t,buffer}.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .filtered_noise import FilteredNoise
+from .harmonic_oscillator import OscillatorBank
+from .reverb import Reverb
+
+
+def _dense_stack(n_in: int, width: int, depth: int) -> nn.Module:
+    """`depth` x (Linear -> LayerNorm -> LeakyReLU), registered as mlp_layer1..N like decoder.py:9-39."""
+    stack = nn.Module()
+    for i in range(depth):
+        block = nn.Sequential(nn.Linear(n_in if i == 0 else width, width), nn.LayerNorm(width), nn.LeakyReLU())
+        stack.add_module(f"mlp_layer{i + 1}", block)
+    stack.depth = depth
+    return stack
+
+
+def _run_stack(stack: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    for i in range(stack.depth):
+        x = getattr(stack, f"mlp_layer{i + 1}")(x)
+    return x
+
+
+def scaled_sigmoid(x: torch.Tensor) -> torch.Tensor:
+    """decoder.py:110-116: 2*sigmoid(x)^ln(10) + 1e-7 (the value range of every synth control)."""
+    return 2.0 * torch.sigmoid(x).pow(2.3026) + 1e-7
+
+
+class Controller(nn.Module):
+    """f0 / loudness features -> control dict {f0, c, a, H, hidden} (decoder.py:41-108)."""
+
+    def __init__(self, conf):
+        super().__init__()
+        width, depth = conf.decoder_mlp_units, conf.decoder_mlp_layers
+        self.mlp_f0 = _dense_stack(1, width, depth)
+        self.mlp_loudness = _dense_stack(1, width, depth)
+        self.gru = nn.GRU(2 * width, conf.decoder_gru_units, conf.decoder_gru_layers, batch_first=True)
+        self.mlp_gru = _dense_stack(conf.decoder_gru_units + 2 * width, width, depth)
+        self.dense_harmonic = nn.Linear(width, conf.n_harmonics)
+        self.dense_loudness = nn.Linear(width, 1)
+        self.dense_filter = nn.Linear(width, conf.n_noise_filters)
+
+    def forward(self, batch, hidden=None):
+        z_pitch = _run_stack(self.mlp_f0, batch['normalized_cents'])
+        z_loud = _run_stack(self.mlp_loudness, batch['loudness'])
+        z = torch.cat((z_pitch, z_loud), dim=-1)
+        z, state = self.gru(z, hidden) if hidden is not None else self.gru(z)
+        z = _run_stack(self.mlp_gru, torch.cat((z, z_pitch, z_loud), dim=-1))
+        controls = dict(f0=batch['f0'], c=scaled_sigmoid(self.dense_harmonic(z)), hidden=state,
+                        H=scaled_sigmoid(self.dense_filter(z)), a=scaled_sigmoid(self.dense_loudness(z)))
+        if hidden is not None:
+            return controls, hidden    # the INPUT state, as the reference returns it
+        return controls
+
+
+class Decoder(nn.Module):
+    """controller -> harmonics + noise -> reverb (decoder.py:119-147), all on the device."""
+
+    def __init__(self, conf, noise_rng: str = 'host', seed: int = 0):
+        super().__init__()
+        self.controller = Controller(conf)
+        self.harmonics = OscillatorBank(conf)
+        self.noise = FilteredNoise(conf, rng=noise_rng, seed=seed)
+        self.reverb = Reverb(conf)
+
+    def synthesize(self, ctrl, live: bool = False):
+        """`harmonics + noise` for a control dict (decoder.py:129-132 / :141-144)."""
+        dry = self.harmonics.live(ctrl) if live else self.harmonics(ctrl)
+        return dry + self.noise(ctrl)
+
+    def forward(self, z):
+        return self.reverb(self.synthesize(self.controller(z)))
+
+    def forward_live(self, z, hidden):
+        ctrl, hidden = self.controller(z, hidden)
+        audio = self.reverb.live_forward(self.synthesize(ctrl, live=True))
+        return audio.cpu().squeeze(0).numpy(), hidden   # one D2H per callback (rt/synth.py:50-52)

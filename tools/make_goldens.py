@@ -275,7 +275,32 @@ def g11():
          rv_decay=rv.decay.numpy(), rv_wet=rv.wet.numpy(), harm=harm.numpy(), noise=noise.numpy(), y=y.numpy())
 
 
+def g12():
+    # controller (decoder.py:41-116), tiny widths: weights + inputs + outputs, incl. the hidden-state pass-through (App. C.7)
+    from model.autoencoder.decoder import Controller as RefController
+
+    class C:
+        n_harmonics, n_noise_filters, sample_rate, hop_length = 8, 9, 16000, 64
+        decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 16, 2, 12, 1
+
+    torch.manual_seed(1212)
+    ctl = RefController(C)
+    rng = np.random.default_rng(112)
+    batch = {"normalized_cents": rng.uniform(0, 1, (2, 6, 1)).astype(np.float32),
+             "loudness": rng.uniform(-1, 1, (2, 6, 1)).astype(np.float32),
+             "f0": rng.uniform(80, 400, (2, 6, 1)).astype(np.float32)}
+    tb = {k: t(v) for k, v in batch.items()}
+    out = ctl(tb)
+    h0 = torch.from_numpy(rng.standard_normal((1, 2, 12)).astype(np.float32))
+    out2, h_ret = ctl(tb, h0)
+    arrays = {f"w__{k}": v.numpy() for k, v in ctl.state_dict().items()}
+    save("g12_controller", **batch, **arrays, c=out["c"].numpy(), a=out["a"].numpy(), H=out["H"].numpy(),
+         hidden=out["hidden"].numpy(), h0=h0.numpy(), c2=out2["c"].numpy(), hidden2=out2["hidden"].numpy(), h_ret=h_ret.numpy())
+
+
 if __name__ == "__main__":
     print("torch", torch.__version__, "threads", torch.get_num_threads())
-    for fn in (g1, g2_g3_g4, g5, g6, g7, g8, g9, g10, g11):
-        fn()
+    only = sys.argv[1:]
+    for fn in (g1, g2_g3_g4, g5, g6, g7, g8, g9, g10, g11, g12):
+        if not only or fn.__name__ in only:
+            fn()
