@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Times the hot path on every single-GPU configuration of BASELINE.json (cfg1..cfg3 + the cfg4 shard) and
+checks a slice of each against the CPU oracle.  Prints one JSON object per config (not the bench.py contract:
+bench.py stays on the metric's configuration)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ddsp_pytorch_amd as ddsp  # noqa: E402
+from ddsp_pytorch_amd import synthetic as syn  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def run(shape, seed, steps=5):
+    ctl = syn.make_controls(shape, seed, "all_live")
+    x = {k: torch.from_numpy(v).cuda() for k, v in ctl.items()}
+
+    def step(i):
+        y, _, _ = ddsp.osc_forward(x["f0"], x["c"], x["a"], shape.hop, shape.sample_rate)
+        ddsp.noise_forward(x["H"], shape.hop, seed=7, offset=i << 32, out=y, accumulate=True)
+        return y
+
+    step(0)
+    ddsp._lib.profile_enable(8 * steps + 8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        y = step(i + 1)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    rec = {}
+    for name, ms in ddsp._lib.profile_read():
+        rec.setdefault(name, []).append(ms)
+    ddsp._lib.profile_enable(0)
+    # parity of row 0 (oscillator only, injected-noise parity is covered by the tests)
+    yo, _, _ = ddsp.osc_forward(x["f0"][:1], x["c"][:1], x["a"][:1], shape.hop, shape.sample_rate)
+    ref = oracle.osc_forward(ctl["f0"][:1], ctl["c"][:1], ctl["a"][:1], shape.hop, shape.sample_rate)
+    err = float(np.max(np.abs(yo.cpu().numpy() - ref)))
+    print(json.dumps({"config": shape.name, "batch": shape.batch, "sample_rate": shape.sample_rate, "hop": shape.hop,
+                      "harmonics": shape.n_harmonics, "noise_bands": shape.n_noise_filters, "ms_per_step": 1e3 * el,
+                      "samples_per_s": shape.batch * shape.samples / el,
+                      "kernel_ms": {k: round(float(np.mean(v)), 4) for k, v in rec.items()},
+                      "max_abs_err_row0_vs_oracle": err}), flush=True)
+
+
+if __name__ == "__main__":
+    cfg2 = syn.CFG2
+    for shape, seed in ((syn.CFG1, 1001), (cfg2, 1002), (syn.CFG3, 1003), (syn.CFG4_PER_GPU, 1004)):
+        run(shape, seed)
