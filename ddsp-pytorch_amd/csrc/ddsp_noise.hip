@@ -29,6 +29,7 @@ struct NoiseParams {
     int B, T, F, R, S;
     uint64_t seed, offset;
     int accumulate;
+    int lpf_log; // batched kernel: log2(lanes per frame) -> 64 >> lpf_log frames per workgroup
     int ablate;  // debug/timing only: bit1 skips the IR phase, bit2 the convolution (results are then wrong)
 };
 
@@ -131,23 +132,26 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int S = p.S, R = p.R, F = p.F, half = S >> 1;
     const int KS = kern_stride(R), XS = xs_stride(R);
+    const int LPF = 1 << p.lpf_log;                     // lanes per frame in the convolution phase
+    const int FB = 64 >> p.lpf_log;                     // frames per workgroup
+    const int HS = FB + 4;                              // row stride of the transposed H tile
     float *ct = smem;                                   // [S] (rounded up to a multiple of 4)
-    float *kern = ct + ((S + 3) & ~3);                  // [64][KS]
-    float *un = kern + kFB * KS;                        // union: Hs [F][64]  |  xs [64][XS]
+    float *kern = ct + ((S + 3) & ~3);                  // [FB][KS]
+    float *un = kern + FB * KS;                         // union: Hs [F][HS]  |  xs [FB][XS]
     float *Hs = un, *xs = un;
     const int tid = threadIdx.x;
-    const long frame0 = (long)blockIdx.x * kFB;
+    const long frame0 = (long)blockIdx.x * FB;
     const long nframes = (long)p.B * p.T;
-    const int nf = (int)min((long)kFB, nframes - frame0);
+    const int nf = (int)min((long)FB, nframes - frame0);
 
     // phase 0
-    for (int e = tid; e < kFB * F; e += kNT) {
+    for (int e = tid; e < FB * F; e += kNT) {
         const int f = e / F, k = e - f * F;              // coalesced global read, transposed (padded) LDS write
-        Hs[k * kHS + f] = (f < nf) ? p.Hm[(frame0 + f) * F + k] : 0.0f;
+        Hs[k * HS + f] = (f < nf) ? p.Hm[(frame0 + f) * F + k] : 0.0f;
     }
     for (int m = tid; m < S; m += kNT) ct[m] = cospif((float)(2 * m) / (float)S);
     if (S < R)                                          // otherwise phase 1 writes every tap
-        for (int e = tid; e < kFB * KS; e += kNT) kern[e] = 0.0f;
+        for (int e = tid; e < FB * KS; e += kNT) kern[e] = 0.0f;
     __syncthreads();
 
     // phase 1
@@ -171,23 +175,23 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
     if (!(p.ablate & 2)) {
         // n = 0 and n = S/2 need no cosines: plain and alternating sums, 8 lanes per frame
         {
-            const int f = tid >> 3, part = tid & 7;
+            const int f = min(tid >> 3, FB - 1), part = tid & 7;
             float e = 0.0f, o = 0.0f;
             for (int k = 1 + part; k < half; k += 8) {
-                const float h = Hs[k * kHS + f];
+                const float h = Hs[k * HS + f];
                 if (k & 1) o += h; else e += h;
             }
 #pragma unroll
             for (int m = 1; m < 8; m <<= 1) { e += __shfl_xor(e, m); o += __shfl_xor(o, m); }
-            if (part == 0) {
-                const float h0 = Hs[f], hn = Hs[half * kHS + f];
+            if (part == 0 && (tid >> 3) < FB) {
+                const float h0 = Hs[f], hn = Hs[half * HS + f];
                 emit(f, 0, __fmaf_rn(2.0f, e + o, h0 + hn) * invS);
                 if (half > 0) emit(f, half, __fmaf_rn(2.0f, e - o, h0 + ((half & 1) ? -hn : hn)) * invS);
             }
         }
         // n = 1 .. S/4 paired with S/2 - n: cos(2 pi k (S/2 - n) / S) = (-1)^k cos(2 pi k n / S)
         const int nmain = half / 2;
-        for (int item = tid; item < nmain * (kFB / 4); item += kNT) {
+        for (int item = tid; item < nmain * (FB / 4); item += kNT) {
             const int fq = item / nmain, n = 1 + item - fq * nmain;  // n fastest: a wavefront's H reads broadcast
             float ev[4] = {0, 0, 0, 0}, ov[4] = {0, 0, 0, 0};
             int idx = 0;
@@ -195,12 +199,12 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
                 idx += n;
                 if (idx >= S) idx -= S;
                 const float c = ct[idx];
-                const float4 h = *reinterpret_cast<const float4 *>(&Hs[k * kHS + 4 * fq]);
+                const float4 h = *reinterpret_cast<const float4 *>(&Hs[k * HS + 4 * fq]);
                 if (k & 1) { ov[0] = __fmaf_rn(h.x, c, ov[0]); ov[1] = __fmaf_rn(h.y, c, ov[1]); ov[2] = __fmaf_rn(h.z, c, ov[2]); ov[3] = __fmaf_rn(h.w, c, ov[3]); }
                 else       { ev[0] = __fmaf_rn(h.x, c, ev[0]); ev[1] = __fmaf_rn(h.y, c, ev[1]); ev[2] = __fmaf_rn(h.z, c, ev[2]); ev[3] = __fmaf_rn(h.w, c, ev[3]); }
             }
             const float4 h0 = *reinterpret_cast<const float4 *>(&Hs[4 * fq]);
-            const float4 hn = *reinterpret_cast<const float4 *>(&Hs[half * kHS + 4 * fq]);
+            const float4 hn = *reinterpret_cast<const float4 *>(&Hs[half * HS + 4 * fq]);
             const float h0v[4] = {h0.x, h0.y, h0.z, h0.w}, hnv[4] = {hn.x, hn.y, hn.z, hn.w};
             const int n2 = half - n;
             const float sg1 = (n & 1) ? -1.0f : 1.0f, sg2 = (n2 & 1) ? -1.0f : 1.0f;
@@ -214,15 +218,15 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
     __syncthreads();
 
     // phase 2 (overwrites the H tile)
-    for (int e = tid; e < kFB * 8; e += kNT) xs[(e >> 3) * XS + (e & 7)] = 0.0f;
+    for (int e = tid; e < FB * 8; e += kNT) xs[(e >> 3) * XS + (e & 7)] = 0.0f;
     if (p.u) {
-        for (int e = tid; e < kFB * R; e += kNT) {
+        for (int e = tid; e < FB * R; e += kNT) {
             const int f = e / R, m = e - f * R;
             xs[f * XS + 8 + m] = (f < nf) ? p.u[(frame0 + f) * R + m] * 2.0f - 1.0f : 0.0f;
         }
     } else {
         const int quads = R >> 2;                        // R % 8 == 0 here
-        for (int e = tid; e < kFB * quads; e += kNT) {
+        for (int e = tid; e < FB * quads; e += kNT) {
             const int f = e / quads, q = e - f * quads;
             const uint64_t ctr = p.offset + (uint64_t)(frame0 + f) * (uint64_t)quads + (uint64_t)q;
             uint32_t r[4];
@@ -237,17 +241,20 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
     }
     __syncthreads();
 
-    // phase 3
+    // phase 3: lane = (frame, sub-chunk); a wavefront owns the groups q and Q-1-q of LPF consecutive 8-sample chunks
     const int lane = tid & 63, wv = tid >> 6;
-    const int C = R >> 3;
-    const float *krow = kern + lane * KS;
-    const float *xrow = xs + lane * XS + 8;
-    float *yrow = p.y + (frame0 + lane) * R;
-    for (int pr = wv; 2 * pr < ((p.ablate & 4) ? 0 : C); pr += kNT / 64) {
+    const int fr = lane >> p.lpf_log, sub = lane & (LPF - 1);
+    const int C = R >> 3, Q = (C + LPF - 1) >> p.lpf_log;
+    const float *krow = kern + fr * KS;
+    const float *xrow = xs + fr * XS + 8;
+    float *yrow = p.y + (frame0 + fr) * R;
+    for (int pr = wv; 2 * pr < ((p.ablate & 4) ? 0 : Q); pr += kNT / 64) {
 #pragma unroll 1
         for (int side = 0; side < 2; ++side) {
-            const int c = side ? C - 1 - pr : pr;
-            if (side && c == pr) break;
+            const int q = side ? Q - 1 - pr : pr;
+            if (side && q == pr) break;
+            const int c = q * LPF + sub;
+            if (c >= C) continue;
             const int n0 = c << 3;
             float acc[8];
 #pragma unroll
@@ -267,7 +274,7 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
 #pragma unroll
                     for (int u = 0; u < 8; ++u) acc[u] = __fmaf_rn(kv[v], xw[8 + u - v], acc[u]);
             }
-            if (lane < nf) {
+            if (fr < nf) {
                 float4 lo = make_float4(acc[0], acc[1], acc[2], acc[3]), hi = make_float4(acc[4], acc[5], acc[6], acc[7]);
                 float4 *dst = reinterpret_cast<float4 *>(yrow + n0);
                 if (p.accumulate) {
@@ -493,12 +500,23 @@ size_t bwd_batched_lds_bytes(int F, int R)
     return sizeof(float) * (((S + 3) & ~3) + (size_t)kFB * (R + 4) + (size_t)kFB * (R + 12) + (size_t)(S / 2 + 1) * kHS);
 }
 
-size_t batched_lds_bytes(int F, int R)
+size_t batched_lds_bytes(int F, int R, int lpf_log)
 {
-    const int S = 2 * (F - 1);
-    const size_t ua = (size_t)kHS * F, ub = (size_t)kFB * (R + 12);
+    const int S = 2 * (F - 1), FB = 64 >> lpf_log;
+    const size_t ua = (size_t)(FB + 4) * F, ub = (size_t)FB * (R + 12);
     const size_t un = ua > ub ? ua : ub;
-    return sizeof(float) * (((S + 3) & ~3) + (size_t)kFB * (R + 4) + un);
+    return sizeof(float) * (((S + 3) & ~3) + (size_t)FB * (R + 4) + un);
+}
+
+// Lanes per frame (log2) of the batched forward kernel: 64 frames per workgroup when the tile fits in ~half the
+// CU's LDS (two workgroups per CU), else 32 / 16 frames; -1 when even 16 frames do not fit (generic kernel then).
+int pick_lpf_log(int F, int R)
+{
+    for (int l = 0; l <= 2; ++l)
+        if (batched_lds_bytes(F, R, l) <= 80 * 1024) return l;
+    for (int l = 0; l <= 2; ++l)
+        if (batched_lds_bytes(F, R, l) <= 160 * 1024) return l;
+    return -1;
 }
 
 }  // namespace
@@ -511,18 +529,21 @@ extern "C" int ddsp_noise_forward(const float *Hmag, const float *uniform, float
     NoiseParams p;
     p.Hm = Hmag; p.u = uniform; p.y = y;
     p.B = B; p.T = T; p.F = F; p.R = hop; p.S = 2 * (F - 1);
-    p.seed = seed; p.offset = offset; p.accumulate = accumulate; p.ablate = g_force_generic & ~1;
+    p.seed = seed; p.offset = offset; p.accumulate = accumulate; p.ablate = g_force_generic & ~1; p.lpf_log = 0;
     if ((long)B * T >= (1L << 31)) return DDSP_ERANGE;
     hipStream_t s = (hipStream_t)stream;
-    const size_t blds = batched_lds_bytes(F, hop);
-    if (!(g_force_generic & 1) && hop % 8 == 0 && blds <= 160 * 1024 && ((uintptr_t)y % 16) == 0) {
+    const int lpf_log = pick_lpf_log(F, hop);
+    if (!(g_force_generic & 1) && hop % 8 == 0 && lpf_log >= 0 && ((uintptr_t)y % 16) == 0) {
+        const size_t blds = batched_lds_bytes(F, hop, lpf_log);
+        p.lpf_log = lpf_log;
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute((const void *)noise_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
-        const long blocks = ((long)B * T + kFB - 1) / kFB;
+        const int fb = 64 >> lpf_log;
+        const long blocks = ((long)B * T + fb - 1) / fb;
         const int slot = ddsp_prof::begin(ddsp_prof::NOISE, s);
         hipLaunchKernelGGL(noise_batched_kernel, dim3((unsigned)blocks), dim3(kNT), blds, s, p);
         ddsp_prof::end(slot, s);

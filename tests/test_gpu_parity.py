@@ -201,7 +201,8 @@ def test_noise_generic_kernel(path):
     assert np.max(np.abs(y.cpu().numpy() - g["y"])) <= 2e-6
 
 
-@pytest.mark.parametrize("hop,nf,B,T", [(128, 65, 3, 70), (64, 65, 2, 33), (256, 129, 1, 65), (128, 33, 1, 64), (8, 5, 2, 9), (136, 7, 1, 5)])
+@pytest.mark.parametrize("hop,nf,B,T", [(128, 65, 3, 70), (64, 65, 2, 33), (256, 129, 1, 65), (128, 33, 1, 64), (8, 5, 2, 9), (136, 7, 1, 5),
+                                         (512, 257, 1, 37), (512, 195, 2, 19), (1024, 65, 1, 9)])
 def test_noise_vs_oracle_ragged_tiles(hop, nf, B, T):
     rng = np.random.default_rng(hop + nf)
     H = syn.controller_range(rng.standard_normal((B, T, nf), dtype=np.float32))
