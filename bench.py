@@ -198,6 +198,16 @@ def main():
         launch_samples = shape.batch * shape.samples
         achieved = launch_samples * bytes_per_sample / (synth_ms * 1e-3) / 1e9
         hs_per_s = launch_samples * shape.n_harmonics / (synth_ms * 1e-3)
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc.json")
+        if os.path.exists(pmc_file) and not args.batch and not args.tiling:
+            # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (not measurable live)
+            try:
+                k = [v for n, v in json.load(open(pmc_file)).items() if n.startswith("osc_synth_kernel") and "hbm_bytes_per_launch" in v]
+                if k:
+                    traffic, traffic_src = max(x["hbm_bytes_per_launch"] for x in k), "profiles/r01_pmc.json (FETCH_SIZE x2 + WRITE_SIZE)"
+            except Exception:  # noqa: BLE001
+                pass
         line = {
             "metric": "audio samples/sec/GPU + %HBM-roofline, 16kHz/100-harmonic/batch512",
             "value": samples_per_step * args.steps / elapsed,
@@ -213,7 +223,8 @@ def main():
                        "step": "OscillatorBank.forward + FilteredNoise.forward accumulated (harmonics + noise)"},
             "samples_per_sec_per_gpu": samples_per_step * args.steps / elapsed / world,
             "roofline": {"bound": "hbm", "kernel": "osc_frame_synth", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": launch_samples * bytes_per_sample,
                          "algorithmic_bytes_per_sample": bytes_per_sample, "avg_launch_ms": synth_ms,
                          "note": "kernel is VALU-bound (SURVEY §8d): see valu",
                          "valu": {"harmonic_samples_per_s": hs_per_s, "lane_ops_per_harmonic_sample": 12,

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 output of tools/collect_profiles.sh into small, committed summaries:
+   <dir>/<round>_kernel_stats.csv      per-kernel calls / average ns (from --kernel-trace --stats)
+   <dir>/<round>_pmc.json              per-kernel averages of the PMC counters + derived HBM bytes per launch
+   <dir>/<round>_bench.json            the bench.py line of the same run
+HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half
+of the bytes of coalesced streaming reads -> doubled (calibrated here on osc_totals_kernel, whose only large
+read is the [B,T,H] amplitude tensor: 2 x FETCH_SIZE = its byte count); WRITE_SIZE is exact."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+src, rnd = sys.argv[1], sys.argv[2]
+dst = src
+KEYS = ("osc_synth_kernel", "osc_totals_kernel", "osc_supscan_kernel", "noise_batched_kernel", "noise_frame_kernel")
+
+
+def short(name):
+    for k in KEYS:
+        if k in name:
+            tail = name[name.index(k):]
+            return tail.split("(")[0]
+    return None
+
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+rows = []
+if stats:
+    for r in csv.DictReader(open(stats[0])):
+        s = short(r["Name"])
+        if s:
+            rows.append({"kernel": s, "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": int(r["MinNs"]),
+                         "max_ns": int(r["MaxNs"]), "pct": float(r["Percentage"])})
+    with open(os.path.join(dst, f"{rnd}_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for f in glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            s = short(r["Kernel_Name"])
+            if s:
+                pmc[s][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for k, cs in pmc.items():
+    d = {c: sum(v) / len(v) for c, v in cs.items()}
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        d["hbm_read_bytes_per_launch"] = 2.0 * d["FETCH_SIZE"] * 1024.0
+        d["hbm_write_bytes_per_launch"] = d["WRITE_SIZE"] * 1024.0
+        d["hbm_bytes_per_launch"] = d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
+    if d.get("GRBM_GUI_ACTIVE") and d.get("SQ_INSTS_VALU"):
+        d["cycles_per_valu_inst_per_simd"] = (d["GRBM_GUI_ACTIVE"] / 8.0) / (d["SQ_INSTS_VALU"] / 1024.0)
+    out[k] = d
+json.dump(out, open(os.path.join(dst, f"{rnd}_pmc.json"), "w"), indent=1, sort_keys=True)
+try:
+    line = open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1]
+    json.dump(json.loads(line), open(os.path.join(dst, f"{rnd}_bench.json"), "w"), indent=1)
+    print(line[:400])
+except Exception as e:  # noqa: BLE001
+    print("no bench line:", e)
+for r in rows:
+    print(r)
+for k, d in out.items():
+    print(k, {c: f"{v:.4g}" for c, v in d.items()})
