@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--f0", default="all_live", choices=["all_live", "musical"])
     ap.add_argument("--batch", type=int, default=0, help="rows per GPU (default: the metric's 512)")
     ap.add_argument("--tiling", type=int, default=0, help="force harmonics per lane (tuning)")
+    ap.add_argument("--harmonics", type=int, default=0, help="override the number of harmonics (tuning experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="synth", choices=["synth", "train"],
                     help="synth: the headline hot path; train: BASELINE.json configs[4] (decoder + MSS loss + Adam, "
@@ -147,9 +148,9 @@ def main():
     if args.mode == "train":
         return train_mode(args, rank, world, dist)
     shape = syn.CFG4_PER_GPU
-    if args.batch:
-        shape = syn.SynthShape(shape.name, args.batch, shape.sample_rate, shape.hop, shape.frames, shape.n_harmonics,
-                               shape.n_noise_filters)
+    if args.batch or args.harmonics:
+        shape = syn.SynthShape(shape.name, args.batch or shape.batch, shape.sample_rate, shape.hop, shape.frames,
+                               args.harmonics or shape.n_harmonics, shape.n_noise_filters)
     ctl = syn.make_controls(shape, 1004 + rank, args.f0)
     x = {k: torch.from_numpy(v).cuda() for k, v in ctl.items()}
     conf = Conf(shape)
@@ -200,7 +201,7 @@ def main():
         hs_per_s = launch_samples * shape.n_harmonics / (synth_ms * 1e-3)
         traffic, traffic_src = None, None
         pmc_file = os.path.join(ROOT, "profiles", "r01_pmc.json")
-        if os.path.exists(pmc_file) and not args.batch and not args.tiling:
+        if os.path.exists(pmc_file) and not args.batch and not args.tiling and not args.harmonics:
             # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (not measurable live)
             try:
                 k = [v for n, v in json.load(open(pmc_file)).items() if n.startswith("osc_synth_kernel") and "hbm_bytes_per_launch" in v]

@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_DIR, "libddsp_hip.so")
+SO_PATH = os.environ.get("DDSP_HIP_LIB", os.path.join(_DIR, "libddsp_hip.so"))  # override: A/B builds (tools/ab_bench.sh)
 ABI_VERSION = 1
 
 _lib = None

@@ -38,38 +38,66 @@ __device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st,
 {
     const float i0f = (float)i0;
     float *yrow = p.y + (long)b * p.T * p.R;
+    // Each stage is one instruction TYPE over the lane's K harmonics; the scheduling barriers keep the stages
+    // apart: runs of same-type VALU instructions issue ~10 % faster on gfx950 than the interleaved chains
+    // (tools/microbench/valu_rates.hip: "chain staged" vs "osc chain").
+#define DDSP_STAGE_END() __builtin_amdgcn_sched_barrier(0)
     for (int n = n_beg; n < n_end; ++n) {
         const int i = t * p.R + n;
         float w0, w1;
         upsample_weights(p.scale, i, i0f, w0, w1);
         float v[K];
+        DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < K; ++m) v[m] = __fmaf_rn(w0, st.x0[m], w1 * st.x1[m]);  // fl32(fma(w0,x[i0],fl32(w1*x[i1])))
+        for (int m = 0; m < K; ++m) v[m] = w1 * st.x1[m];
+        DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < K; ++m) st.acc[m] += (double)v[m];                        // :41 double accumulator
+        for (int m = 0; m < K; ++m) v[m] = __fmaf_rn(w0, st.x0[m], v[m]);           // fl32(fma(w0,x[i0],fl32(w1*x[i1])))
+        DDSP_STAGE_END();
+        double d[K];
+#pragma unroll
+        for (int m = 0; m < K; ++m) d[m] = (double)v[m];
+        DDSP_STAGE_END();
+#pragma unroll
+        for (int m = 0; m < K; ++m) st.acc[m] += d[m];                               // :41 double accumulator
+        DDSP_STAGE_END();
         if (MODE == MODE_SYNTH) {
 #pragma unroll
             for (int m = 0; m < K; ++m) v[m] = (float)st.acc[m];                      // ... rounded to fp32 per sample
+            DDSP_STAGE_END();
+            // P - q*2pi32 is exact in fp32 for q = rint(P/2pi32 +- 0.25) < 2^21: r in (-4.8, 4.8).  Taking the
+            // nearest multiple instead of the floor changes sin(r) by <= |2pi32 - 2pi| = 1.75e-7.
+            float q[K];
 #pragma unroll
-            for (int m = 0; m < K; ++m) {
-                // P - q*2pi32 is exact in fp32 for q = rint(P/2pi32 +- 0.25) < 2^21: r in (-4.8, 4.8).  Taking the
-                // nearest multiple instead of the floor changes sin(r) by <= |2pi32 - 2pi| = 1.75e-7.
-                const float q = __fmaf_rn(v[m], kInvTwoPi32, kRoundMagic) - kRoundMagic;
-                v[m] = __fmaf_rn(-q, kTwoPi32, v[m]);                                 // :42
-            }
+            for (int m = 0; m < K; ++m) q[m] = __fmaf_rn(v[m], kInvTwoPi32, kRoundMagic);
+            DDSP_STAGE_END();
 #pragma unroll
-            for (int m = 0; m < K; ++m) v[m] = __builtin_amdgcn_sinf(v[m] * kRevPerRad);  // v_sin_f32 (revolutions)
+            for (int m = 0; m < K; ++m) q[m] = q[m] - kRoundMagic;
+            DDSP_STAGE_END();
+#pragma unroll
+            for (int m = 0; m < K; ++m) v[m] = __fmaf_rn(-q[m], kTwoPi32, v[m]);     // :42
+            DDSP_STAGE_END();
+#pragma unroll
+            for (int m = 0; m < K; ++m) v[m] = v[m] * kRevPerRad;
+            DDSP_STAGE_END();
+#pragma unroll
+            for (int m = 0; m < K; ++m) v[m] = __builtin_amdgcn_sinf(v[m]);           // v_sin_f32 (revolutions)
+            DDSP_STAGE_END();
+#pragma unroll
+            for (int m = 0; m < K; ++m) q[m] = __fmaf_rn(w1, st.da[m], st.a0[m]);
+            DDSP_STAGE_END();
             float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
             for (int m = 0; m < K; ++m) {
-                const float A = __fmaf_rn(w1, st.da[m], st.a0[m]);
-                if (m & 1) s1 = __fmaf_rn(A, v[m], s1); else s0 = __fmaf_rn(A, v[m], s0);  // :48-49
+                if (m & 1) s1 = __fmaf_rn(q[m], v[m], s1); else s0 = __fmaf_rn(q[m], v[m], s0);  // :48-49
             }
+            DDSP_STAGE_END();
             const float sum = group_sum(s0 + s1, p.logG);
             const float L = __fmaf_rn(w0, L0, w1 * L1);
             if (j == 0 && active) yrow[i] = L * sum;
         }
     }
+#undef DDSP_STAGE_END
 }
 
 // Reference-exact walk: libm fmodf modulo, live offsets (:70), live state and debug phase outputs.

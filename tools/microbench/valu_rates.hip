@@ -11,10 +11,10 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-constexpr int ITERS = 1 << 16;
+constexpr int ITERS = 1 << 14;
 constexpr int UNROLL = 16;  // independent instructions per loop iteration
 
-enum Op { FMA32, MUL32, PKFMA32, ADD64, FMA64, CVT_F64_F32, CVT_F32_F64, SIN32, FLOOR32, CNDMASK, MOVDPP, MIX };
+enum Op { FMA32, MUL32, PKFMA32, ADD64, FMA64, CVT_F64_F32, CVT_F32_F64, SIN32, FLOOR32, CNDMASK, MOVDPP, MIX, MIX_STAGED, MIX_NOSIN, MIX_NO64 };
 
 template <int OP>
 __global__ void __launch_bounds__(256) rate_kernel(float *out, float seed, unsigned long long *stamps)
@@ -29,6 +29,40 @@ __global__ void __launch_bounds__(256) rate_kernel(float *out, float seed, unsig
     for (int u = 0; u < UNROLL; ++u) { f[u] = a + u; d[u] = (double)a + u; p2[u] = make_float2(a + u, a - u); }
     float2 b2 = make_float2(b, b);
     for (int it = 0; it < ITERS; ++it) {
+        if (OP == MIX_STAGED || OP == MIX_NOSIN || OP == MIX_NO64) {
+            // same 12 instructions per chain, issued stage by stage over the 16 chains
+            float t[UNROLL], P[UNROLL], q[UNROLL], r[UNROLL], s[UNROLL];
+            double dd[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t[u]) : "v"(b), "v"(f[u]));
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(t[u]) : "v"(a), "v"(f[u]));
+            if (OP != MIX_NO64) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(dd[u]) : "v"(t[u]));
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[u]) : "v"(dd[u]));
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(P[u]) : "v"(d[u]));
+            } else {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) { asm volatile("v_mul_f32 %0, %1, %2" : "=v"(P[u]) : "v"(b), "v"(t[u])); asm volatile("v_mul_f32 %0, %1, %2" : "=v"(P[u]) : "v"(b), "v"(P[u])); asm volatile("v_mul_f32 %0, %1, %2" : "=v"(P[u]) : "v"(b), "v"(P[u])); }
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(q[u]) : "v"(P[u]), "v"(b), "v"(a));
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(q[u]) : "v"(a));
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r[u]) : "v"(q[u]), "v"(b), "v"(P[u]));
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r[u]) : "v"(b));
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) { if (OP == MIX_NOSIN) asm volatile("v_mul_f32 %0, %1, %1" : "=v"(s[u]) : "v"(r[u])); else asm volatile("v_sin_f32 %0, %1" : "=v"(s[u]) : "v"(r[u])); }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) asm volatile("v_fma_f32 %0, %1, %2, %2" : "=v"(t[u]) : "v"(a), "v"(b));
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(f[u]) : "v"(t[u]), "v"(s[u]));
+        }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             if (OP == FMA32) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[u]) : "v"(b), "v"(a));
@@ -154,6 +188,7 @@ int main()
     float *dout;
     CK(hipMalloc(&dout, 1024));
     if (getenv("SIN_ACC")) sin_accuracy();
+    if (getenv("ONLY_MIX")) { run<MIX>("osc chain x12", 12, dout); run<MIX_STAGED>("chain staged", 12, dout); run<MIX_NOSIN>("staged, no sin", 12, dout); run<MIX_NO64>("staged, no f64", 12, dout); return 0; }
     run<FMA32>("v_fma_f32", 1, dout);
     run<MUL32>("v_mul_f32", 1, dout);
     run<PKFMA32>("v_pk_fma_f32", 1, dout);
@@ -166,5 +201,8 @@ int main()
     run<CNDMASK>("v_cndmask_b32", 1, dout);
     run<MOVDPP>("v_add_f32_dpp", 1, dout);
     run<MIX>("osc chain x12", 12, dout);
+    run<MIX_STAGED>("chain staged", 12, dout);
+    run<MIX_NOSIN>("staged, no sin", 12, dout);
+    run<MIX_NO64>("staged, no f64", 12, dout);
     return 0;
 }
