@@ -32,20 +32,34 @@ namespace {
 
 // Production walk over samples [n_beg, n_end) of frame t, written stage by stage over the lane's K harmonics
 // so that the K independent dependency chains interleave.
-template <int K, int MODE>
+template <int K, int MODE, bool POW2>
 __device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st, int b, int t, int j, bool active,
                                           int i0, float L0, float L1, int n_beg, int n_end)
 {
     const float i0f = (float)i0;
-    float *yrow = p.y + (long)b * p.T * p.R;
+    float *yframe = p.y + ((long)b * p.T + t) * p.R;
+    // POW2 (hop a power of two, clip <= 2^23 samples): the interpolation weight is an exact dyadic rational that
+    // advances by exactly 1/hop per sample (0 while the source index is clamped at the clip start), so it is
+    // carried incrementally -- bit-identical to the reference's expression -- and the loop bounds are wave-uniform.
+    float lam = 0.0f, dlam = 0.0f;
+    if (POW2) {
+        float w0s;
+        upsample_weights(p.scale, t * p.R + n_beg, i0f, w0s, lam);
+        dlam = (t == 0 && n_beg == 0) ? 0.0f : p.scale;
+    }
     // Each stage is one instruction TYPE over the lane's K harmonics; the scheduling barriers keep the stages
     // apart: runs of same-type VALU instructions issue ~10 % faster on gfx950 than the interleaved chains
     // (tools/microbench/valu_rates.hip: "chain staged" vs "osc chain").
 #define DDSP_STAGE_END() __builtin_amdgcn_sched_barrier(0)
     for (int n = n_beg; n < n_end; ++n) {
-        const int i = t * p.R + n;
         float w0, w1;
-        upsample_weights(p.scale, i, i0f, w0, w1);
+        if (POW2) {
+            w1 = lam;
+            w0 = 1.0f - lam;
+            lam += dlam;
+        } else {
+            upsample_weights(p.scale, t * p.R + n, i0f, w0, w1);
+        }
         float v[K];
         DDSP_STAGE_END();
 #pragma unroll
@@ -94,7 +108,7 @@ __device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st,
             DDSP_STAGE_END();
             const float sum = group_sum(s0 + s1, p.logG);
             const float L = __fmaf_rn(w0, L0, w1 * L1);
-            if (j == 0 && active) yrow[i] = L * sum;
+            if (j == 0 && active) yframe[n] = L * sum;
         }
     }
 #undef DDSP_STAGE_END
@@ -139,7 +153,7 @@ __device__ __forceinline__ void walk_exact(const OscParams &p, FrameState<K> &st
 
 // ---- pass 1: frame totals + superblock-local exclusive scan ----------------------------------------
 // One workgroup = one superblock = 256/G consecutive frames of ONE batch row (grid = B * NSB).
-template <int K, bool LIVE>
+template <int K, bool LIVE, bool POW2>
 __global__ void __launch_bounds__(256) osc_totals_kernel(OscParams p)
 {
     extern __shared__ double tot_s[];  // [FPB][H]
@@ -205,15 +219,19 @@ __global__ void __launch_bounds__(256) osc_totals_kernel(OscParams p)
     const int split = split_index(t, p.R, p.scale);
     if (LIVE) {
         walk_exact<K, MODE_TOTALS>(p, st, lp, b, t, j, active, ia, 0.0f, 0.0f, 0, split);
+    } else if (POW2) {
+        walk_fast<K, MODE_TOTALS, true>(p, st, b, t, j, active, ia, 0.0f, 0.0f, 0, p.R >> 1);
     } else {
-        walk_fast<K, MODE_TOTALS>(p, st, b, t, j, active, ia, 0.0f, 0.0f, 0, split);
+        walk_fast<K, MODE_TOTALS, false>(p, st, b, t, j, active, ia, 0.0f, 0.0f, 0, split);
     }
 #pragma unroll
     for (int m = 0; m < K; ++m) { st.x0[m] = st.x1[m]; st.x1[m] = xc[m]; }
     if (LIVE) {
         walk_exact<K, MODE_TOTALS>(p, st, lp, b, t, j, active, ib, 0.0f, 0.0f, split, p.R);
+    } else if (POW2) {
+        walk_fast<K, MODE_TOTALS, true>(p, st, b, t, j, active, ib, 0.0f, 0.0f, p.R >> 1, p.R);
     } else {
-        walk_fast<K, MODE_TOTALS>(p, st, b, t, j, active, ib, 0.0f, 0.0f, split, p.R);
+        walk_fast<K, MODE_TOTALS, false>(p, st, b, t, j, active, ib, 0.0f, 0.0f, split, p.R);
     }
     // exclusive scan over the superblock's frames, one thread per harmonic column (exact: fp64 sums of fp32 values)
 #pragma unroll
@@ -251,7 +269,7 @@ __global__ void __launch_bounds__(256) osc_supscan_kernel(OscParams p)
 }
 
 // ---- pass 3: synthesis ------------------------------------------------------------------------------
-template <int K, int VARIANT>
+template <int K, int VARIANT, bool POW2>
 __global__ void __launch_bounds__(256) osc_synth_kernel(OscParams p)
 {
     if (VARIANT == VAR_EXACT && !p.force_exact && *p.redo_flag == 0) return;
@@ -293,9 +311,11 @@ __global__ void __launch_bounds__(256) osc_synth_kernel(OscParams p)
     float L0, L1;
     if (VARIANT == VAR_FAST) {
         load_synth_segment<K>(p, st, b, j, ia, ib, L0, L1);
-        walk_fast<K, MODE_SYNTH>(p, st, b, t, j, active, ia, L0, L1, 0, split);
+        if (POW2) walk_fast<K, MODE_SYNTH, true>(p, st, b, t, j, active, ia, L0, L1, 0, p.R >> 1);
+        else      walk_fast<K, MODE_SYNTH, false>(p, st, b, t, j, active, ia, L0, L1, 0, split);
         load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);
-        walk_fast<K, MODE_SYNTH>(p, st, b, t, j, active, ib, L0, L1, split, p.R);
+        if (POW2) walk_fast<K, MODE_SYNTH, true>(p, st, b, t, j, active, ib, L0, L1, p.R >> 1, p.R);
+        else      walk_fast<K, MODE_SYNTH, false>(p, st, b, t, j, active, ib, L0, L1, split, p.R);
     } else {
         float lp[K];
 #pragma unroll
@@ -320,28 +340,38 @@ hipError_t launch_frames(const OscParams &p, hipStream_t s)
     const size_t lds = (sizeof(double) * (size_t)(256 >> p.logG) + sizeof(float) * (size_t)((256 >> p.logG) + 2)) * p.H;
     static bool lds_attr_set = false;  // superblocks of 256 short frames need more than the default 64 KiB
     if (!lds_attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)osc_totals_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)osc_totals_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
+        const void *fns[] = {(const void *)osc_totals_kernel<K, true, false>, (const void *)osc_totals_kernel<K, false, false>,
+                             (const void *)osc_totals_kernel<K, false, true>};
+        for (const void *fn : fns) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
         lds_attr_set = true;
     }
+    const dim3 tgrid((unsigned)(p.B * p.NSB)), blk(256);
     int slot = ddsp_prof::begin(ddsp_prof::TOTALS, s);
     if (p.live_in) {
-        hipLaunchKernelGGL((osc_totals_kernel<K, true>), dim3((unsigned)(p.B * p.NSB)), dim3(256), lds, s, p);
+        hipLaunchKernelGGL((osc_totals_kernel<K, true, false>), tgrid, blk, lds, s, p);
+    } else if (p.pow2) {
+        hipLaunchKernelGGL((osc_totals_kernel<K, false, true>), tgrid, blk, lds, s, p);
     } else {
-        hipLaunchKernelGGL((osc_totals_kernel<K, false>), dim3((unsigned)(p.B * p.NSB)), dim3(256), lds, s, p);
+        hipLaunchKernelGGL((osc_totals_kernel<K, false, false>), tgrid, blk, lds, s, p);
     }
     ddsp_prof::end(slot, s);
     slot = ddsp_prof::begin(ddsp_prof::SCAN, s);
     hipLaunchKernelGGL(osc_supscan_kernel, dim3((unsigned)(((long)p.B * p.H + 255) / 256)), dim3(256), 0, s, p);
     ddsp_prof::end(slot, s);
     slot = ddsp_prof::begin(ddsp_prof::SYNTH, s);
-    if (!live && !p.force_exact)
-        hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST>), dim3(grid), dim3(256), 0, s, p);
+    if (!live && !p.force_exact) {
+        if (p.pow2) {
+            hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST, true>), dim3(grid), blk, 0, s, p);
+        } else {
+            hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST, false>), dim3(grid), blk, 0, s, p);
+        }
+    }
     ddsp_prof::end(slot, s);
     // exits at once unless a wavefront of the FAST kernel raised redo_flag (or exactness is forced)
-    hipLaunchKernelGGL((osc_synth_kernel<K, VAR_EXACT>), dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((osc_synth_kernel<K, VAR_EXACT, false>), dim3(grid), blk, 0, s, p);
     return hipGetLastError();
 }
 
@@ -405,6 +435,7 @@ bool setup_params(OscParams &p, void *scratch, int B, int T, int H, int hop, int
     p.scale = (float)(1.0 / (double)hop);
     p.nyquist = (float)(sample_rate / 2);
     p.sr = (float)sample_rate;
+    p.pow2 = ((hop & (hop - 1)) == 0 && hop >= 2 && (long)T * hop <= (1L << 23)) ? 1 : 0;
     return true;
 }
 
