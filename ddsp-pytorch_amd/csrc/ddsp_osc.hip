@@ -115,7 +115,7 @@ __device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st,
 }
 
 // Reference-exact walk: libm fmodf modulo, live offsets (:70), live state and debug phase outputs.
-template <int K, int MODE>
+template <int K, int MODE, bool FAST_MOD = false>
 __device__ __forceinline__ void walk_exact(const OscParams &p, FrameState<K> &st, const float (&lp)[K], int b, int t,
                                            int j, bool active, int i0, float L0, float L1, int n_beg, int n_end)
 {
@@ -135,9 +135,17 @@ __device__ __forceinline__ void walk_exact(const OscParams &p, FrameState<K> &st
             st.acc[m] += (double)inc;
             if (MODE == MODE_SYNTH) {
                 const float P = (float)st.acc[m];
-                const float r = remainder_two_pi(P);              // :42, exact
-                if (p.dbg_phi && active && h < p.H) p.dbg_phi[((long)b * N + i) * p.H + h] = r;
-                if (p.live_out && active && b == 0 && i == N - 1 && h < p.H) p.live_out[h] = r;  // :72
+                float r;
+                if (FAST_MOD) {
+                    // live calls inside the fast modulo's range: exact remainder only for the state that is kept (:72)
+                    const float q = __fmaf_rn(P, kInvTwoPi32, kRoundMagic) - kRoundMagic;
+                    r = __fmaf_rn(-q, kTwoPi32, P);
+                    if (p.live_out && active && b == 0 && i == N - 1 && h < p.H) p.live_out[h] = remainder_two_pi(P);
+                } else {
+                    r = remainder_two_pi(P);                      // :42, exact
+                    if (p.dbg_phi && active && h < p.H) p.dbg_phi[((long)b * N + i) * p.H + h] = r;
+                    if (p.live_out && active && b == 0 && i == N - 1 && h < p.H) p.live_out[h] = r;  // :72
+                }
                 const float s = __builtin_amdgcn_sinf(r * kRevPerRad);
                 const float A = __fmaf_rn(w1, st.da[m], st.a0[m]);
                 sum = __fmaf_rn(A, s, sum);
@@ -323,10 +331,17 @@ __global__ void __launch_bounds__(256) osc_synth_kernel(OscParams p)
             const int h = j + m * G;
             lp[m] = (h < p.H && b == 0 && p.live_in) ? p.live_in[h] : 0.0f;
         }
-        load_synth_segment<K>(p, st, b, j, ia, ib, L0, L1);
-        walk_exact<K, MODE_SYNTH>(p, st, lp, b, t, j, active, ia, L0, L1, 0, split);
-        load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);
-        walk_exact<K, MODE_SYNTH>(p, st, lp, b, t, j, active, ib, L0, L1, split, p.R);
+        if (fast && !p.dbg_phi) {
+            load_synth_segment<K>(p, st, b, j, ia, ib, L0, L1);
+            walk_exact<K, MODE_SYNTH, true>(p, st, lp, b, t, j, active, ia, L0, L1, 0, split);
+            load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);
+            walk_exact<K, MODE_SYNTH, true>(p, st, lp, b, t, j, active, ib, L0, L1, split, p.R);
+        } else {
+            load_synth_segment<K>(p, st, b, j, ia, ib, L0, L1);
+            walk_exact<K, MODE_SYNTH>(p, st, lp, b, t, j, active, ia, L0, L1, 0, split);
+            load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);
+            walk_exact<K, MODE_SYNTH>(p, st, lp, b, t, j, active, ib, L0, L1, split, p.R);
+        }
     }
 }
 
@@ -386,17 +401,21 @@ namespace ddsp_osc {
 // wavefronts per SIMD (>= 200 VGPRs), which costs about 10 %.
 const int kKs[] = {4, 8, 12, 13, 15, 16, 20, 23, 25};
 
-double tiling_cost(int H, int K, int logG)
+double tiling_cost(int H, int K, int logG, long frames)
 {
     const double waste = (double)((1 << logG) * K) / (double)H;
     const double shared = 1.0 + (0.5 + 0.08 * logG) / (double)K;
     const double occupancy = K >= 20 ? 1.10 : (K >= 15 ? 1.03 : 1.0);
-    return waste * shared * occupancy;
+    // small problems (the real-time path: a handful of frames) cannot fill 256 CUs x 4 SIMDs x 2 wavefronts:
+    // there the run time is one wavefront's walk, proportional to K, so fewer harmonics per lane win
+    const double waves = (double)(frames << logG) / 64.0;
+    const double fill = waves >= 2048.0 ? 1.0 : (waves < 1.0 ? 1.0 : waves) / 2048.0;
+    return waste * shared * occupancy / fill;
 }
 
 int g_forced_k = 0;  // ddsp_osc_set_tiling: 0 = automatic
 
-bool pick_tiling(int H, Tiling *out)
+bool pick_tiling(int H, long frames, Tiling *out)
 {
     double best = 1e30;
     bool found = false;
@@ -406,7 +425,7 @@ bool pick_tiling(int H, Tiling *out)
         int logG = 0;
         while ((1 << logG) < lanes) ++logG;
         if (logG > 6) continue;
-        const double cost = tiling_cost(H, K, logG);
+        const double cost = tiling_cost(H, K, logG, frames);
         if (cost < best) {
             best = cost;
             out->K = K;
@@ -420,7 +439,7 @@ bool pick_tiling(int H, Tiling *out)
 bool setup_params(OscParams &p, void *scratch, int B, int T, int H, int hop, int sample_rate)
 {
     Tiling tl;
-    if (!pick_tiling(H, &tl)) return false;
+    if (!pick_tiling(H, (long)B * T, &tl)) return false;
     const size_t n = (size_t)B * T * H;
     char *base = (char *)scratch;
     p.w = (float *)base;

@@ -144,7 +144,7 @@ __device__ __forceinline__ void load_synth_segment(const OscParams &p, FrameStat
 
 // ---- host side (defined in ddsp_osc.hip) ---------------------------------------------------------------
 struct Tiling { int K, logG; };
-bool pick_tiling(int H, Tiling *out);
+bool pick_tiling(int H, long frames, Tiling *out);
 inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 // scratch layout: w | amp | loc | sup | flag; sup is sized for the smallest superblock (G = 64: 4 frames)
 inline size_t sup_elems(int B, int T, int H) { return (size_t)B * ((size_t)(T + 3) / 4) * H; }

@@ -280,3 +280,45 @@ def test_noise_grad_device_rng_consistent():
     y1 = fn2({"H": dev(Hp)})
     fd = float(((y1 - y0) * gy).sum()) / eps
     assert abs(fd - float(H.grad[0, 2, 7])) <= 2e-3 * max(1.0, abs(fd))
+
+
+# ---- edge shapes ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,T,H,hop,sr", [(1, 1, 1, 1, 8000), (2, 3, 1, 2, 8000), (1, 2, 5, 1, 16000), (3, 9, 27, 48, 22050),
+                                          (1, 4, 180, 512, 44100), (2, 5, 300, 32, 48000), (1, 3, 1600, 8, 48000),
+                                          (7, 33, 64, 96, 16000), (1, 700, 3, 16, 16000)])
+def test_osc_edge_shapes_vs_oracle(B, T, H, hop, sr):
+    rng = np.random.default_rng(B * 1000 + T * 10 + H)
+    f0 = rng.uniform(5, max(10.0, 0.6 * sr / max(H, 2)), (B, T, 1)).astype(np.float32)
+    c = syn.controller_range(rng.standard_normal((B, T, H), dtype=np.float32))
+    a = syn.controller_range(rng.standard_normal((B, T, 1), dtype=np.float32))
+    ref, d = oracle.osc_forward(f0, c, a, hop, sr, debug=True)
+    y, _, phi = ddsp.osc_forward(dev(f0), dev(c), dev(a), hop, sr, debug_phases=True)
+    assert np.array_equal(bits(phi.cpu().numpy()), bits(d["phi"]))
+    assert np.max(np.abs(y.cpu().numpy() - ref)) <= TOL_Y
+    y2, _, _ = ddsp.osc_forward(dev(f0), dev(c), dev(a), hop, sr)
+    assert np.max(np.abs(y2.cpu().numpy() - ref)) <= TOL_Y
+
+
+def test_shape_limits_are_reported_not_computed():
+    L = ddsp._lib.lib()
+    x = torch.zeros(4, device="cuda")
+    p = x.data_ptr()
+    # 1601 harmonics: no tiling; T*hop >= 2^24: sample indices not exact in fp32
+    assert L.ddsp_osc_forward(p, p, p, p, p, None, None, None, 1, 1, 1601, 1, 16000, None) == -2
+    assert L.ddsp_osc_forward(p, p, p, p, p, None, None, None, 1, 1 << 14, 1, 1 << 10, 16000, None) == -2
+    assert L.ddsp_noise_forward(p, None, p, 1, 1, 1, 8, 0, 0, 0, None) == -1          # F < 2
+    with pytest.raises(ValueError):
+        ddsp.noise_forward(torch.zeros(1, 2, 5, device="cuda"), 8, uniform=torch.zeros(1, 2, 7, device="cuda"))
+    empty = ddsp.osc_forward(torch.zeros(0, 3, 1, device="cuda"), torch.zeros(0, 3, 4, device="cuda"),
+                             torch.zeros(0, 3, 1, device="cuda"), 8, 16000)[0]
+    assert empty.shape == (0, 24)
+
+
+@pytest.mark.parametrize("nf,hop", [(2, 8), (3, 8), (2, 5), (9, 16), (130, 8)])
+def test_noise_edge_shapes_vs_oracle(nf, hop):
+    rng = np.random.default_rng(nf * 100 + hop)
+    H = syn.controller_range(rng.standard_normal((2, 5, nf), dtype=np.float32))
+    u = rng.random((2, 5, hop), dtype=np.float32)
+    ref = oracle.noise_forward(H, u, hop)
+    y = ddsp.noise_forward(dev(H), hop, uniform=dev(u))
+    assert np.max(np.abs(y.cpu().numpy() - ref)) <= 2e-6

@@ -49,7 +49,35 @@ def run(shape, seed, steps=5):
                       "max_abs_err_row0_vs_oracle": err}), flush=True)
 
 
+def run_live(calls=200):
+    """The rt path (rt/synth.py:40-55): OscillatorBank.live + FilteredNoise per callback, B=1, 4 frames of 512 samples
+    at 44.1 kHz, 180 harmonics, 195 noise bands (config/default.py:11-19).  Deadline: 2048/44100 s = 46.4 ms."""
+    shape = syn.SynthShape("rt_live_default", 1, 44100, 512, 4, 180, 195)
+
+    class Conf:
+        n_harmonics, sample_rate, hop_length = 180, 44100, 512
+
+    osc = ddsp.OscillatorBank(Conf).cuda()
+    noise = ddsp.FilteredNoise(Conf, rng="device")
+    ctl = syn.make_controls(shape, 5, "musical")
+    x = {k: torch.from_numpy(v).cuda() for k, v in ctl.items()}
+    with torch.no_grad():
+        for _ in range(5):
+            y = osc.live(x) + noise(x)
+        torch.cuda.synchronize()
+        lat = []
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            y = osc.live(x) + noise(x)
+            out = y.cpu()                      # the callback needs the samples on the host
+            lat.append(time.perf_counter() - t0)
+    lat = np.array(lat) * 1e3
+    print(json.dumps({"config": shape.name, "samples_per_call": shape.samples, "latency_ms_median": float(np.median(lat)),
+                      "latency_ms_p99": float(np.percentile(lat, 99)), "deadline_ms": 1e3 * 2048 / 44100}), flush=True)
+
+
 if __name__ == "__main__":
+    run_live()
     cfg2 = syn.CFG2
     for shape, seed in ((syn.CFG1, 1001), (cfg2, 1002), (syn.CFG3, 1003), (syn.CFG4_PER_GPU, 1004)):
         run(shape, seed)
