@@ -32,7 +32,9 @@ namespace {
 
 // Production walk over samples [n_beg, n_end) of frame t, written stage by stage over the lane's K harmonics
 // so that the K independent dependency chains interleave.
-template <int K, int MODE, bool POW2>
+// KL <= K: only the lane's first KL harmonic slots are walked (the others are silent in this frame, see
+// osc_synth_kernel).
+template <int K, int MODE, bool POW2, int KL = K>
 __device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st, int b, int t, int j, bool active,
                                           int i0, float L0, float L1, int n_beg, int n_end)
 {
@@ -60,49 +62,49 @@ __device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st,
         } else {
             upsample_weights(p.scale, t * p.R + n, i0f, w0, w1);
         }
-        float v[K];
+        float v[KL];
         DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < K; ++m) v[m] = w1 * st.x1[m];
+        for (int m = 0; m < KL; ++m) v[m] = w1 * st.x1[m];
         DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < K; ++m) v[m] = __fmaf_rn(w0, st.x0[m], v[m]);           // fl32(fma(w0,x[i0],fl32(w1*x[i1])))
+        for (int m = 0; m < KL; ++m) v[m] = __fmaf_rn(w0, st.x0[m], v[m]);           // fl32(fma(w0,x[i0],fl32(w1*x[i1])))
         DDSP_STAGE_END();
-        double d[K];
+        double d[KL];
 #pragma unroll
-        for (int m = 0; m < K; ++m) d[m] = (double)v[m];
+        for (int m = 0; m < KL; ++m) d[m] = (double)v[m];
         DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < K; ++m) st.acc[m] += d[m];                               // :41 double accumulator
+        for (int m = 0; m < KL; ++m) st.acc[m] += d[m];                               // :41 double accumulator
         DDSP_STAGE_END();
         if (MODE == MODE_SYNTH) {
 #pragma unroll
-            for (int m = 0; m < K; ++m) v[m] = (float)st.acc[m];                      // ... rounded to fp32 per sample
+            for (int m = 0; m < KL; ++m) v[m] = (float)st.acc[m];                      // ... rounded to fp32 per sample
             DDSP_STAGE_END();
             // P - q*2pi32 is exact in fp32 for q = rint(P/2pi32 +- 0.25) < 2^21: r in (-4.8, 4.8).  Taking the
             // nearest multiple instead of the floor changes sin(r) by <= |2pi32 - 2pi| = 1.75e-7.
-            float q[K];
+            float q[KL];
 #pragma unroll
-            for (int m = 0; m < K; ++m) q[m] = __fmaf_rn(v[m], kInvTwoPi32, kRoundMagic);
+            for (int m = 0; m < KL; ++m) q[m] = __fmaf_rn(v[m], kInvTwoPi32, kRoundMagic);
             DDSP_STAGE_END();
 #pragma unroll
-            for (int m = 0; m < K; ++m) q[m] = q[m] - kRoundMagic;
+            for (int m = 0; m < KL; ++m) q[m] = q[m] - kRoundMagic;
             DDSP_STAGE_END();
 #pragma unroll
-            for (int m = 0; m < K; ++m) v[m] = __fmaf_rn(-q[m], kTwoPi32, v[m]);     // :42
+            for (int m = 0; m < KL; ++m) v[m] = __fmaf_rn(-q[m], kTwoPi32, v[m]);     // :42
             DDSP_STAGE_END();
 #pragma unroll
-            for (int m = 0; m < K; ++m) v[m] = v[m] * kRevPerRad;
+            for (int m = 0; m < KL; ++m) v[m] = v[m] * kRevPerRad;
             DDSP_STAGE_END();
 #pragma unroll
-            for (int m = 0; m < K; ++m) v[m] = __builtin_amdgcn_sinf(v[m]);           // v_sin_f32 (revolutions)
+            for (int m = 0; m < KL; ++m) v[m] = __builtin_amdgcn_sinf(v[m]);           // v_sin_f32 (revolutions)
             DDSP_STAGE_END();
 #pragma unroll
-            for (int m = 0; m < K; ++m) q[m] = __fmaf_rn(w1, st.da[m], st.a0[m]);
+            for (int m = 0; m < KL; ++m) q[m] = __fmaf_rn(w1, st.da[m], st.a0[m]);
             DDSP_STAGE_END();
             float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
-            for (int m = 0; m < K; ++m) {
+            for (int m = 0; m < KL; ++m) {
                 if (m & 1) s1 = __fmaf_rn(q[m], v[m], s1); else s0 = __fmaf_rn(q[m], v[m], s0);  // :48-49
             }
             DDSP_STAGE_END();
@@ -168,7 +170,6 @@ __global__ void __launch_bounds__(256) osc_totals_kernel(OscParams p)
     const int G = 1 << p.logG, FPB = 256 >> p.logG;
     const int b = blockIdx.x / p.NSB, sb = blockIdx.x - b * p.NSB;
     const int fl = threadIdx.x >> p.logG, j = threadIdx.x & (G - 1);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *p.redo_flag = 0;
     int t = sb * FPB + fl;
     const bool active = t < p.T;
     if (!active) t = p.T - 1;
@@ -185,6 +186,7 @@ __global__ void __launch_bounds__(256) osc_totals_kernel(OscParams p)
         const float *crow = p.c + (rowbase + t) * p.H;
         float a0[K];
         float s = 0.0f;
+        bool silent = false;
 #pragma unroll
         for (int m = 0; m < K; ++m) {
             const int h = j + m * G;
@@ -192,7 +194,12 @@ __global__ void __launch_bounds__(256) osc_totals_kernel(OscParams p)
             const float hz = (float)(h + 1) * fb;
             a0[m] = (ok && !(hz > p.nyquist)) ? crow[h] : 0.0f;   // :31-32 strict >, integer Nyquist
             s += a0[m];
+            silent = silent || (ok && a0[m] == 0.0f);
         }
+        // (read first: one atomic per batch instead of one per wavefront on the same address; a stale read only repeats it)
+        if (__any(silent && active) && (threadIdx.x & 63) == 0 &&
+            __hip_atomic_load(p.redo_flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            atomicOr(p.redo_flag + 1, 1);
         s = group_sum(s, p.logG);                                 // any summation order: App. A item 2
         const float rs = 1.0f / s;                                // amp = a0 * (1/s): <= 1 ulp from a0/s (:33); 0 * inf = NaN
 #pragma unroll
@@ -277,10 +284,14 @@ __global__ void __launch_bounds__(256) osc_supscan_kernel(OscParams p)
 }
 
 // ---- pass 3: synthesis ------------------------------------------------------------------------------
-template <int K, int VARIANT, bool POW2>
+// SKIP: the variant that stops at the highest audible harmonic slot; the totals kernel raises redo_flag[1] when the
+// batch has any silent (masked / zero-amplitude) harmonic, and exactly one of the SKIP / non-SKIP launches runs
+// (the other exits on the flag), so an all-audible batch pays nothing for the extra code.
+template <int K, int VARIANT, bool POW2, bool SKIP>
 __global__ void __launch_bounds__(256) osc_synth_kernel(OscParams p)
 {
     if (VARIANT == VAR_EXACT && !p.force_exact && *p.redo_flag == 0) return;
+    if (VARIANT == VAR_FAST && POW2 && (p.redo_flag[1] != 0) != SKIP) return;
     const int G = 1 << p.logG;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const int j = threadIdx.x & (G - 1);
@@ -318,12 +329,35 @@ __global__ void __launch_bounds__(256) osc_synth_kernel(OscParams p)
     const int split = split_index(t, p.R, p.scale);
     float L0, L1;
     if (VARIANT == VAR_FAST) {
-        load_synth_segment<K>(p, st, b, j, ia, ib, L0, L1);
-        if (POW2) walk_fast<K, MODE_SYNTH, true>(p, st, b, t, j, active, ia, L0, L1, 0, p.R >> 1);
-        else      walk_fast<K, MODE_SYNTH, false>(p, st, b, t, j, active, ia, L0, L1, 0, split);
-        load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);
-        if (POW2) walk_fast<K, MODE_SYNTH, true>(p, st, b, t, j, active, ib, L0, L1, p.R >> 1, p.R);
-        else      walk_fast<K, MODE_SYNTH, false>(p, st, b, t, j, active, ib, L0, L1, split, p.R);
+        // Harmonics whose amplitude is exactly zero at all three bracketing frames (above Nyquist: :31-32) are silent
+        // for the whole frame and their phase is not needed either (every frame starts from the scanned totals), so
+        // the walk stops at the highest slot that is audible anywhere in the wavefront: 1/4, 1/2 or all of K.
+        constexpr int KQ = (K + 3) / 4, KH = (K + 1) / 2;
+        int mlive = K;
+        if (SKIP) {
+            mlive = 0;
+            const float *ab = p.amp + (long)b * p.T * p.H;
+#pragma unroll
+            for (int m = 0; m < K; ++m) {
+                const int h = j + m * G;
+                bool nz = false;
+                if (h < p.H) nz = (ab[(long)ia * p.H + h] != 0.0f) || (ab[(long)ib * p.H + h] != 0.0f) || (ab[(long)ic * p.H + h] != 0.0f);
+                if (__any(nz)) mlive = m + 1;   // NaN amplitudes (all-masked frame) compare != 0: kept
+            }
+        }
+#define DDSP_WALK2(KL)                                                                                       \
+        do {                                                                                                 \
+            load_synth_segment<K>(p, st, b, j, ia, ib, L0, L1);                                              \
+            if (POW2) walk_fast<K, MODE_SYNTH, true, KL>(p, st, b, t, j, active, ia, L0, L1, 0, p.R >> 1);   \
+            else      walk_fast<K, MODE_SYNTH, false, KL>(p, st, b, t, j, active, ia, L0, L1, 0, split);     \
+            load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);                                              \
+            if (POW2) walk_fast<K, MODE_SYNTH, true, KL>(p, st, b, t, j, active, ib, L0, L1, p.R >> 1, p.R); \
+            else      walk_fast<K, MODE_SYNTH, false, KL>(p, st, b, t, j, active, ib, L0, L1, split, p.R);   \
+        } while (0)
+        if (SKIP && mlive <= KQ) DDSP_WALK2(KQ);
+        else if (SKIP && mlive <= KH) DDSP_WALK2(KH);
+        else DDSP_WALK2(K);
+#undef DDSP_WALK2
     } else {
         float lp[K];
 #pragma unroll
@@ -364,6 +398,8 @@ hipError_t launch_frames(const OscParams &p, hipStream_t s)
         lds_attr_set = true;
     }
     const dim3 tgrid((unsigned)(p.B * p.NSB)), blk(256);
+    hipError_t me = hipMemsetAsync(p.redo_flag, 0, 2 * sizeof(int), s);  // [0] redo-exact, [1] batch has silent harmonics
+    if (me != hipSuccess) return me;
     int slot = ddsp_prof::begin(ddsp_prof::TOTALS, s);
     if (p.live_in) {
         hipLaunchKernelGGL((osc_totals_kernel<K, true, false>), tgrid, blk, lds, s, p);
@@ -379,14 +415,15 @@ hipError_t launch_frames(const OscParams &p, hipStream_t s)
     slot = ddsp_prof::begin(ddsp_prof::SYNTH, s);
     if (!live && !p.force_exact) {
         if (p.pow2) {
-            hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST, true>), dim3(grid), blk, 0, s, p);
+            hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST, true, false>), dim3(grid), blk, 0, s, p);
+            hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST, true, true>), dim3(grid), blk, 0, s, p);
         } else {
-            hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST, false>), dim3(grid), blk, 0, s, p);
+            hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST, false, false>), dim3(grid), blk, 0, s, p);
         }
     }
     ddsp_prof::end(slot, s);
     // exits at once unless a wavefront of the FAST kernel raised redo_flag (or exactness is forced)
-    hipLaunchKernelGGL((osc_synth_kernel<K, VAR_EXACT, false>), dim3(grid), blk, 0, s, p);
+    hipLaunchKernelGGL((osc_synth_kernel<K, VAR_EXACT, false, false>), dim3(grid), blk, 0, s, p);
     return hipGetLastError();
 }
 
