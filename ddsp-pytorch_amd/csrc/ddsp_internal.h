@@ -8,3 +8,17 @@ enum KernelId { PREP = 0, TOTALS = 1, SCAN = 2, SYNTH = 3, NOISE = 4 };
 int begin(int kernel_id, hipStream_t s);
 void end(int slot, hipStream_t s);
 }  // namespace ddsp_prof
+
+// One-time (per device of this process) opt-in of a kernel to more than 64 KiB of dynamic LDS.
+// `done` is the caller's static per-device table.  Benign if two threads race: the attribute is idempotent.
+inline hipError_t ddsp_allow_big_lds(const void *fn, bool (&done)[64])
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    dev &= 63;
+    if (done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done[dev] = true;
+    return e;
+}

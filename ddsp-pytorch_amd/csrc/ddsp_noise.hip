@@ -111,8 +111,9 @@ __global__ void __launch_bounds__(256) noise_frame_kernel(NoiseParams p)
 }
 
 
-// ---- batched kernel: 64 frames per workgroup, lane = frame ------------------------------------------
-// Used when hop % 8 == 0 and the tile fits in LDS.  512 threads = 8 wavefronts.
+// ---- batched kernel: FB = 64, 32 or 16 frames per workgroup ------------------------------------------
+// Used when hop % 8 == 0 and a tile fits in LDS.  512 threads = 8 wavefronts.  FB = 64 (lane = frame)
+// while the tile fits in half the CU's LDS (hop <= 128); larger hops take 32 / 16 frames with 2 / 4 lanes per frame.
 //   phase 0  H tile -> LDS transposed [k][frame]; cos table
 //   phase 1  zero-phase IR by direct inverse real DFT, 4 frames per thread, using
 //            cos(2*pi*k*(S/2-n)/S) = (-1)^k cos(2*pi*k*n/S): one pass over k yields z[n] and z[S/2-n];
@@ -536,12 +537,9 @@ extern "C" int ddsp_noise_forward(const float *Hmag, const float *uniform, float
     if (!(g_force_generic & 1) && hop % 8 == 0 && lpf_log >= 0 && ((uintptr_t)y % 16) == 0) {
         const size_t blds = batched_lds_bytes(F, hop, lpf_log);
         p.lpf_log = lpf_log;
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void *)noise_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+        static bool attr_set[64] = {};
+        const hipError_t ae = ddsp_allow_big_lds((const void *)noise_batched_kernel, attr_set);
+        if (ae != hipSuccess) return (int)ae;
         const int fb = 64 >> lpf_log;
         const long blocks = ((long)B * T + fb - 1) / fb;
         const int slot = ddsp_prof::begin(ddsp_prof::NOISE, s);
@@ -576,12 +574,9 @@ extern "C" int ddsp_noise_backward(const float *grad_y, const float *uniform, fl
     hipStream_t s = (hipStream_t)stream;
     const size_t blds = bwd_batched_lds_bytes(F, hop);
     if (!(g_force_generic & 1) && hop % 8 == 0 && blds <= 160 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void *)noise_bwd_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+        static bool attr_set[64] = {};
+        const hipError_t ae = ddsp_allow_big_lds((const void *)noise_bwd_batched_kernel, attr_set);
+        if (ae != hipSuccess) return (int)ae;
         const long blocks = ((long)B * T + kFB - 1) / kFB;
         hipLaunchKernelGGL(noise_bwd_batched_kernel, dim3((unsigned)blocks), dim3(kNT), blds, s, p);
         return (int)hipGetLastError();

@@ -387,15 +387,12 @@ hipError_t launch_frames(const OscParams &p, hipStream_t s)
     const unsigned grid = (unsigned)((lanes + 255) / 256);
     const bool live = p.live_in || p.live_out;
     const size_t lds = (sizeof(double) * (size_t)(256 >> p.logG) + sizeof(float) * (size_t)((256 >> p.logG) + 2)) * p.H;
-    static bool lds_attr_set = false;  // superblocks of 256 short frames need more than the default 64 KiB
-    if (!lds_attr_set) {
-        const void *fns[] = {(const void *)osc_totals_kernel<K, true, false>, (const void *)osc_totals_kernel<K, false, false>,
-                             (const void *)osc_totals_kernel<K, false, true>};
-        for (const void *fn : fns) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-        }
-        lds_attr_set = true;
+    static bool lds_attr_set[3][64] = {};  // superblocks of 256 short frames need more than the default 64 KiB
+    const void *fns[3] = {(const void *)osc_totals_kernel<K, true, false>, (const void *)osc_totals_kernel<K, false, false>,
+                          (const void *)osc_totals_kernel<K, false, true>};
+    for (int i = 0; i < 3; ++i) {
+        const hipError_t e = ddsp_allow_big_lds(fns[i], lds_attr_set[i]);
+        if (e != hipSuccess) return e;
     }
     const dim3 tgrid((unsigned)(p.B * p.NSB)), blk(256);
     hipError_t me = hipMemsetAsync(p.redo_flag, 0, 2 * sizeof(int), s);  // [0] redo-exact, [1] batch has silent harmonics
