@@ -322,3 +322,23 @@ def test_noise_edge_shapes_vs_oracle(nf, hop):
     ref = oracle.noise_forward(H, u, hop)
     y = ddsp.noise_forward(dev(H), hop, uniform=dev(u))
     assert np.max(np.abs(y.cpu().numpy() - ref)) <= 2e-6
+
+
+def test_launch_from_worker_thread_on_side_stream():
+    # rt/synth.py calls forward_live from the JACK callback thread: launches must work off the main thread
+    # and follow the caller's current stream
+    import threading
+    g = load_golden("g3_osc_cfg2_musical")
+    x = {k: dev(g[k]) for k in ("f0", "c", "a")}
+    out = {}
+
+    def worker():
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            y, _, _ = ddsp.osc_forward(x["f0"], x["c"], x["a"], int(g["hop"]), int(g["sample_rate"]))
+            out["y"] = y.cpu()
+
+    th = threading.Thread(target=worker)
+    th.start()
+    th.join()
+    assert np.max(np.abs(out["y"].numpy() - g["y"])) <= TOL_Y
