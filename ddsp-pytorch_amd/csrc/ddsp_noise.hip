@@ -146,11 +146,11 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
     const int nf = (int)min((long)FB, nframes - frame0);
 
     // phase 0
-    for (int e = tid; e < FB * F; e += kNT) {
+    for (int e = tid; e < ((p.ablate & 16) ? 0 : FB * F); e += kNT) {
         const int f = e / F, k = e - f * F;              // coalesced global read, transposed (padded) LDS write
         Hs[k * HS + f] = (f < nf) ? p.Hm[(frame0 + f) * F + k] : 0.0f;
     }
-    for (int m = tid; m < S; m += kNT) ct[m] = cospif((float)(2 * m) / (float)S);
+    for (int m = tid; m < ((p.ablate & 32) ? 0 : S); m += kNT) ct[m] = cospif((float)(2 * m) / (float)S);
     if (S < R)                                          // otherwise phase 1 writes every tap
         for (int e = tid; e < FB * KS; e += kNT) kern[e] = 0.0f;
     __syncthreads();
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
         }
     } else {
         const int quads = R >> 2;                        // R % 8 == 0 here
-        for (int e = tid; e < FB * quads; e += kNT) {
+        for (int e = tid; e < ((p.ablate & 8) ? 0 : FB * quads); e += kNT) {
             const int f = e / quads, q = e - f * quads;
             const uint64_t ctr = p.offset + (uint64_t)(frame0 + f) * (uint64_t)quads + (uint64_t)q;
             uint32_t r[4];
@@ -513,9 +513,13 @@ size_t batched_lds_bytes(int F, int R, int lpf_log)
 // CU's LDS (two workgroups per CU), else 32 / 16 frames; -1 when even 16 frames do not fit (generic kernel then).
 int pick_lpf_log(int F, int R)
 {
-    for (int l = 0; l <= 2; ++l)
+    if (g_force_generic >> 8) return (g_force_generic >> 8) - 1;  // tuning: ddsp_noise_set_generic((l + 1) << 8)
+    // measured (hop 128, F 65): 32 frames / 35 KB per workgroup (4 workgroups per CU) beats 64 frames / 70 KB by 14 %
+    for (int l = 0; l <= 3; ++l)
+        if (batched_lds_bytes(F, R, l) <= 40 * 1024) return l;
+    for (int l = 0; l <= 3; ++l)
         if (batched_lds_bytes(F, R, l) <= 80 * 1024) return l;
-    for (int l = 0; l <= 2; ++l)
+    for (int l = 0; l <= 3; ++l)
         if (batched_lds_bytes(F, R, l) <= 160 * 1024) return l;
     return -1;
 }
@@ -530,7 +534,7 @@ extern "C" int ddsp_noise_forward(const float *Hmag, const float *uniform, float
     NoiseParams p;
     p.Hm = Hmag; p.u = uniform; p.y = y;
     p.B = B; p.T = T; p.F = F; p.R = hop; p.S = 2 * (F - 1);
-    p.seed = seed; p.offset = offset; p.accumulate = accumulate; p.ablate = g_force_generic & ~1; p.lpf_log = 0;
+    p.seed = seed; p.offset = offset; p.accumulate = accumulate; p.ablate = g_force_generic & 0xFE; p.lpf_log = 0;
     if ((long)B * T >= (1L << 31)) return DDSP_ERANGE;
     hipStream_t s = (hipStream_t)stream;
     const int lpf_log = pick_lpf_log(F, hop);
