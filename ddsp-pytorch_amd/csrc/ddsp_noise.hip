@@ -168,8 +168,11 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
             else       { if (nn == 0) continue;    src = half - nn; }
             if (src >= taps) continue;
             const float win = 0.5f - 0.5f * ct[src];      // torch.hann_window(S), periodic
-            int jj = (src - half) % R;                    // roll(-S/2) on the length-R buffer
-            if (jj < 0) jj += R;
+            // roll(-S/2) on the length-R buffer: jj = (src - S/2) mod R = nn or (-nn) mod R (no division when nn <= R)
+            int jj;
+            if (!wrap) jj = nn;                           // nn + S/2 < taps <= R  =>  nn < R
+            else if (nn < R) jj = R - nn;
+            else jj = (R - nn % R) % R;
             kern[f * KS + jj] = z * win;
         }
     };
