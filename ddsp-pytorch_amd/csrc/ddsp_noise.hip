@@ -199,6 +199,7 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
             const int fq = item / nmain, n = 1 + item - fq * nmain;  // n fastest: a wavefront's H reads broadcast
             float ev[4] = {0, 0, 0, 0}, ov[4] = {0, 0, 0, 0};
             int idx = 0;
+#pragma unroll 4
             for (int k = 1; k < half; ++k) {
                 idx += n;
                 if (idx >= S) idx -= S;

@@ -38,6 +38,7 @@ template <int K, int MODE, bool POW2, int KL = K>
 __device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st, int b, int t, int j, bool active,
                                           int i0, float L0, float L1, int n_beg, int n_end)
 {
+    extern __shared__ float ystage[];  // [256/G][32] output staging (synth kernels launched with stage_out)
     const float i0f = (float)i0;
     float *yframe = p.y + ((long)b * p.T + t) * p.R;
     // POW2 (hop a power of two, clip <= 2^23 samples): the interpolation weight is an exact dyadic rational that
@@ -110,7 +111,31 @@ __device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st,
             DDSP_STAGE_END();
             const float sum = group_sum(s0 + s1, p.logG);
             const float L = __fmaf_rn(w0, L0, w1 * L1);
-            if (j == 0 && active) yframe[n] = L * sum;
+            const float out = L * sum;
+            if (POW2 && MODE == MODE_SYNTH && p.stage_out) {
+                // Stage 32 samples per frame in LDS and flush them as one 128-byte line per group: a 4-byte store per
+                // sample makes the L2 allocate (and fetch) every output line long before it is completely written.
+                float *ys = ystage + (threadIdx.x >> p.logG) * 32;
+                if (j == 0) ys[n & 31] = out;
+                if ((n & 31) == 31) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const int per = 32 >> p.logG;            // floats per lane: 8, 4 or 2 (G = 4, 8, 16)
+                    float *dst = yframe + (n - 31) + j * per;
+                    if (active) {
+                        if (per == 8) {
+                            reinterpret_cast<float4 *>(dst)[0] = reinterpret_cast<const float4 *>(ys + j * 8)[0];
+                            reinterpret_cast<float4 *>(dst)[1] = reinterpret_cast<const float4 *>(ys + j * 8)[1];
+                        } else if (per == 4) {
+                            reinterpret_cast<float4 *>(dst)[0] = reinterpret_cast<const float4 *>(ys + j * 4)[0];
+                        } else {
+                            reinterpret_cast<float2 *>(dst)[0] = reinterpret_cast<const float2 *>(ys + j * 2)[0];
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+            } else if (j == 0 && active) {
+                yframe[n] = out;
+            }
         }
     }
 #undef DDSP_STAGE_END
@@ -412,8 +437,9 @@ hipError_t launch_frames(const OscParams &p, hipStream_t s)
     slot = ddsp_prof::begin(ddsp_prof::SYNTH, s);
     if (!live && !p.force_exact) {
         if (p.pow2) {
-            hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST, true, false>), dim3(grid), blk, 0, s, p);
-            hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST, true, true>), dim3(grid), blk, 0, s, p);
+            const size_t ylds = p.stage_out ? sizeof(float) * 32 * (256 >> p.logG) : 0;
+            hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST, true, false>), dim3(grid), blk, ylds, s, p);
+            hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST, true, true>), dim3(grid), blk, ylds, s, p);
         } else {
             hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST, false, false>), dim3(grid), blk, 0, s, p);
         }
@@ -489,6 +515,7 @@ bool setup_params(OscParams &p, void *scratch, int B, int T, int H, int hop, int
     p.nyquist = (float)(sample_rate / 2);
     p.sr = (float)sample_rate;
     p.pow2 = ((hop & (hop - 1)) == 0 && hop >= 2 && (long)T * hop <= (1L << 23)) ? 1 : 0;
+    p.stage_out = (p.pow2 && hop >= 64 && tl.logG >= 2 && tl.logG <= 4) ? 1 : 0;
     return true;
 }
 

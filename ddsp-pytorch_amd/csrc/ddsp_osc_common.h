@@ -32,6 +32,7 @@ struct OscParams {
     int logG;         // lanes per frame group
     int NSB;          // superblocks per batch row = ceil(T / (256 >> logG))
     int force_exact;
+    int stage_out;    // synth: stage 32 output samples per frame in LDS, store whole 128-byte lines (pow2 hop >= 64, G in 4..16)
     int pow2;         // hop is a power of two and the clip has <= 2^23 samples: incremental weights, uniform loops
     float scale;      // fl32(1/R): F.interpolate's source-index scale
     float nyquist;    // float(sample_rate // 2)
