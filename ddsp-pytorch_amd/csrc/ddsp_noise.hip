@@ -30,7 +30,6 @@ struct NoiseParams {
     uint64_t seed, offset;
     int accumulate;
     int lpf_log; // batched kernel: log2(lanes per frame) -> 64 >> lpf_log frames per workgroup
-    int ablate;  // debug/timing only: bit1 skips the IR phase, bit2 the convolution (results are then wrong)
 };
 
 // Philox4x32-10 (Salmon et al. 2011), counter = (c0,c1,0,0), key = seed.
@@ -146,11 +145,11 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
     const int nf = (int)min((long)FB, nframes - frame0);
 
     // phase 0
-    for (int e = tid; e < ((p.ablate & 16) ? 0 : FB * F); e += kNT) {
+    for (int e = tid; e < FB * F; e += kNT) {
         const int f = e / F, k = e - f * F;              // coalesced global read, transposed (padded) LDS write
         Hs[k * HS + f] = (f < nf) ? p.Hm[(frame0 + f) * F + k] : 0.0f;
     }
-    for (int m = tid; m < ((p.ablate & 32) ? 0 : S); m += kNT) ct[m] = cospif((float)(2 * m) / (float)S);
+    for (int m = tid; m < S; m += kNT) ct[m] = cospif((float)(2 * m) / (float)S);
     if (S < R)                                          // otherwise phase 1 writes every tap
         for (int e = tid; e < FB * KS; e += kNT) kern[e] = 0.0f;
     __syncthreads();
@@ -176,7 +175,7 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
             kern[f * KS + jj] = z * win;
         }
     };
-    if (!(p.ablate & 2)) {
+    {
         // n = 0 and n = S/2 need no cosines: plain and alternating sums, 8 lanes per frame
         {
             const int f = min(tid >> 3, FB - 1), part = tid & 7;
@@ -231,7 +230,7 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
         }
     } else {
         const int quads = R >> 2;                        // R % 8 == 0 here
-        for (int e = tid; e < ((p.ablate & 8) ? 0 : FB * quads); e += kNT) {
+        for (int e = tid; e < FB * quads; e += kNT) {
             const int f = e / quads, q = e - f * quads;
             const uint64_t ctr = p.offset + (uint64_t)(frame0 + f) * (uint64_t)quads + (uint64_t)q;
             uint32_t r[4];
@@ -253,7 +252,7 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
     const float *krow = kern + fr * KS;
     const float *xrow = xs + fr * XS + 8;
     float *yrow = p.y + (frame0 + fr) * R;
-    for (int pr = wv; 2 * pr < ((p.ablate & 4) ? 0 : Q); pr += kNT / 64) {
+    for (int pr = wv; 2 * pr < Q; pr += kNT / 64) {
 #pragma unroll 1
         for (int side = 0; side < 2; ++side) {
             const int q = side ? Q - 1 - pr : pr;
@@ -538,7 +537,7 @@ extern "C" int ddsp_noise_forward(const float *Hmag, const float *uniform, float
     NoiseParams p;
     p.Hm = Hmag; p.u = uniform; p.y = y;
     p.B = B; p.T = T; p.F = F; p.R = hop; p.S = 2 * (F - 1);
-    p.seed = seed; p.offset = offset; p.accumulate = accumulate; p.ablate = g_force_generic & 0xFE; p.lpf_log = 0;
+    p.seed = seed; p.offset = offset; p.accumulate = accumulate; p.lpf_log = 0;
     if ((long)B * T >= (1L << 31)) return DDSP_ERANGE;
     hipStream_t s = (hipStream_t)stream;
     const int lpf_log = pick_lpf_log(F, hop);
