@@ -33,6 +33,8 @@ __device__ __forceinline__ void walk_bwd(const OscParams &p, FrameState<K> &st, 
                                          int n_beg, int n_end)
 {
     const float i0f = (float)i0;
+    // stage-ordered like the forward synth walk (ddsp_osc.hip: walk_fast): one instruction type at a time over the K harmonics
+#define DDSP_STAGE_END() __builtin_amdgcn_sched_barrier(0)
     for (int n = n_beg; n < n_end; ++n) {
         const int i = t * p.R + n;
         float w0, w1;
@@ -40,36 +42,68 @@ __device__ __forceinline__ void walk_bwd(const OscParams &p, FrameState<K> &st, 
         const float gi = g_lds ? g_lds[n] : g_glb[n];
         const float gl = gi * __fmaf_rn(w0, L0, w1 * L1);
         float v[K];
+        DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < K; ++m) v[m] = __fmaf_rn(w0, st.x0[m], w1 * st.x1[m]);
+        for (int m = 0; m < K; ++m) v[m] = w1 * st.x1[m];
+        DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < K; ++m) st.acc[m] += (double)v[m];
+        for (int m = 0; m < K; ++m) v[m] = __fmaf_rn(w0, st.x0[m], v[m]);
+        DDSP_STAGE_END();
+        double d[K];
+#pragma unroll
+        for (int m = 0; m < K; ++m) d[m] = (double)v[m];
+        DDSP_STAGE_END();
+#pragma unroll
+        for (int m = 0; m < K; ++m) st.acc[m] += d[m];
+        DDSP_STAGE_END();
 #pragma unroll
         for (int m = 0; m < K; ++m) v[m] = (float)st.acc[m];
+        DDSP_STAGE_END();
+        if (EXACT) {
 #pragma unroll
-        for (int m = 0; m < K; ++m) {
-            if (EXACT) {
-                v[m] = remainder_two_pi_call(v[m]);
-            } else {
-                const float q = __fmaf_rn(v[m], kInvTwoPi32, kRoundMagic) - kRoundMagic;
-                v[m] = __fmaf_rn(-q, kTwoPi32, v[m]);
-            }
+            for (int m = 0; m < K; ++m) v[m] = remainder_two_pi_call(v[m]);
+        } else {
+            float q[K];
+#pragma unroll
+            for (int m = 0; m < K; ++m) q[m] = __fmaf_rn(v[m], kInvTwoPi32, kRoundMagic);
+            DDSP_STAGE_END();
+#pragma unroll
+            for (int m = 0; m < K; ++m) q[m] = q[m] - kRoundMagic;
+            DDSP_STAGE_END();
+#pragma unroll
+            for (int m = 0; m < K; ++m) v[m] = __fmaf_rn(-q[m], kTwoPi32, v[m]);
         }
+        DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < K; ++m) v[m] = __builtin_amdgcn_sinf(v[m] * kRevPerRad);
+        for (int m = 0; m < K; ++m) v[m] = v[m] * kRevPerRad;
+        DDSP_STAGE_END();
+#pragma unroll
+        for (int m = 0; m < K; ++m) v[m] = __builtin_amdgcn_sinf(v[m]);
+        DDSP_STAGE_END();
+        float A[K];
+#pragma unroll
+        for (int m = 0; m < K; ++m) A[m] = __fmaf_rn(w1, st.da[m], st.a0[m]);
+        DDSP_STAGE_END();
         float u0 = 0.0f, u1 = 0.0f;
 #pragma unroll
         for (int m = 0; m < K; ++m) {
-            const float A = __fmaf_rn(w1, st.da[m], st.a0[m]);
-            if (m & 1) u1 = __fmaf_rn(A, v[m], u1); else u0 = __fmaf_rn(A, v[m], u0);
-            const float tq = gl * v[m];
-            plo[m] = __fmaf_rn(w0, tq, plo[m]);
-            phi[m] = __fmaf_rn(w1, tq, phi[m]);
+            if (m & 1) u1 = __fmaf_rn(A[m], v[m], u1); else u0 = __fmaf_rn(A[m], v[m], u0);
         }
+        DDSP_STAGE_END();
+#pragma unroll
+        for (int m = 0; m < K; ++m) v[m] = gl * v[m];
+        DDSP_STAGE_END();
+#pragma unroll
+        for (int m = 0; m < K; ++m) plo[m] = __fmaf_rn(w0, v[m], plo[m]);
+        DDSP_STAGE_END();
+#pragma unroll
+        for (int m = 0; m < K; ++m) phi[m] = __fmaf_rn(w1, v[m], phi[m]);
+        DDSP_STAGE_END();
         const float gu = gi * group_sum(u0 + u1, p.logG);
         galo = __fmaf_rn(w0, gu, galo);
         gahi = __fmaf_rn(w1, gu, gahi);
     }
+#undef DDSP_STAGE_END
 }
 
 template <int K>
