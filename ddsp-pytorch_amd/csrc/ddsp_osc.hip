@@ -33,12 +33,14 @@ namespace {
 // Production walk over samples [n_beg, n_end) of frame t, written stage by stage over the lane's K harmonics
 // so that the K independent dependency chains interleave.
 // KL <= K: only the lane's first KL harmonic slots are walked (the others are silent in this frame, see
-// osc_synth_kernel).
-template <int K, int MODE, bool POW2, int KL = K>
+// osc_synth_kernel).  NS consecutive samples are advanced per iteration: a stage then covers NS*KL independent
+// instructions, which keeps the short walks (KL = K/4, K/2) from stalling on the latency of the previous stage;
+// only the fp64 accumulate is carried from sample to sample.  (segment lengths must be multiples of NS)
+template <int K, int MODE, bool POW2, int KL = K, int NS = 1>
 __device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st, int b, int t, int j, bool active,
                                           int i0, float L0, float L1, int n_beg, int n_end)
 {
-    extern __shared__ float ystage[];  // [256/G][32] output staging (synth kernels launched with stage_out)
+    extern __shared__ float ystage[];  // [32][256 + 4] per-lane partial outputs (synth kernels launched with stage_out)
     const float i0f = (float)i0;
     float *yframe = p.y + ((long)b * p.T + t) * p.R;
     // POW2 (hop a power of two, clip <= 2^23 samples): the interpolation weight is an exact dyadic rational that
@@ -50,95 +52,151 @@ __device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st,
         upsample_weights(p.scale, t * p.R + n_beg, i0f, w0s, lam);
         dlam = (t == 0 && n_beg == 0) ? 0.0f : p.scale;
     }
-    // Each stage is one instruction TYPE over the lane's K harmonics; the scheduling barriers keep the stages
+    // Each stage is one instruction TYPE over the lane's harmonics; the scheduling barriers keep the stages
     // apart: runs of same-type VALU instructions issue ~10 % faster on gfx950 than the interleaved chains
     // (tools/microbench/valu_rates.hip: "chain staged" vs "osc chain").
 #define DDSP_STAGE_END() __builtin_amdgcn_sched_barrier(0)
-    for (int n = n_beg; n < n_end; ++n) {
-        float w0, w1;
-        if (POW2) {
-            w1 = lam;
-            w0 = 1.0f - lam;
-            lam += dlam;
-        } else {
-            upsample_weights(p.scale, t * p.R + n, i0f, w0, w1);
+    // LDS operations of one wavefront execute in order, so the staging buffer needs no s_waitcnt between lane 0's
+    // writes and the group's reads -- only the compiler must not reorder them.  (A wavefront-scope fence here also
+    // waits for the global stores of the previous flush: measured 2x slowdown of the short walks.)
+#define DDSP_WAVE_ORDER() do { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
+    for (int n = n_beg; n < n_end; n += NS) {
+        float w0[NS], w1[NS];
+#pragma unroll
+        for (int e = 0; e < NS; ++e) {
+            if (POW2) {
+                w1[e] = lam;
+                w0[e] = 1.0f - lam;
+                lam += dlam;
+            } else {
+                upsample_weights(p.scale, t * p.R + n + e, i0f, w0[e], w1[e]);
+            }
         }
-        float v[KL];
+        float v[NS][KL];
         DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < KL; ++m) v[m] = w1 * st.x1[m];
+        for (int e = 0; e < NS; ++e)
+#pragma unroll
+            for (int m = 0; m < KL; ++m) v[e][m] = w1[e] * st.x1[m];
         DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < KL; ++m) v[m] = __fmaf_rn(w0, st.x0[m], v[m]);           // fl32(fma(w0,x[i0],fl32(w1*x[i1])))
-        DDSP_STAGE_END();
-        double d[KL];
+        for (int e = 0; e < NS; ++e)
 #pragma unroll
-        for (int m = 0; m < KL; ++m) d[m] = (double)v[m];
+            for (int m = 0; m < KL; ++m) v[e][m] = __fmaf_rn(w0[e], st.x0[m], v[e][m]);  // fl32(fma(w0,x[i0],fl32(w1*x[i1])))
+        DDSP_STAGE_END();
+        double d[NS][KL];
+#pragma unroll
+        for (int e = 0; e < NS; ++e)
+#pragma unroll
+            for (int m = 0; m < KL; ++m) d[e][m] = (double)v[e][m];
         DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < KL; ++m) st.acc[m] += d[m];                               // :41 double accumulator
+        for (int e = 0; e < NS; ++e)
+#pragma unroll
+            for (int m = 0; m < KL; ++m) {
+                st.acc[m] += d[e][m];                                                // :41 double accumulator
+                d[e][m] = st.acc[m];
+            }
         DDSP_STAGE_END();
         if (MODE == MODE_SYNTH) {
 #pragma unroll
-            for (int m = 0; m < KL; ++m) v[m] = (float)st.acc[m];                      // ... rounded to fp32 per sample
+            for (int e = 0; e < NS; ++e)
+#pragma unroll
+                for (int m = 0; m < KL; ++m) v[e][m] = (float)d[e][m];               // ... rounded to fp32 per sample
             DDSP_STAGE_END();
             // P - q*2pi32 is exact in fp32 for q = rint(P/2pi32 +- 0.25) < 2^21: r in (-4.8, 4.8).  Taking the
             // nearest multiple instead of the floor changes sin(r) by <= |2pi32 - 2pi| = 1.75e-7.
-            float q[KL];
+            float q[NS][KL];
 #pragma unroll
-            for (int m = 0; m < KL; ++m) q[m] = __fmaf_rn(v[m], kInvTwoPi32, kRoundMagic);
+            for (int e = 0; e < NS; ++e)
+#pragma unroll
+                for (int m = 0; m < KL; ++m) q[e][m] = __fmaf_rn(v[e][m], kInvTwoPi32, kRoundMagic);
             DDSP_STAGE_END();
 #pragma unroll
-            for (int m = 0; m < KL; ++m) q[m] = q[m] - kRoundMagic;
+            for (int e = 0; e < NS; ++e)
+#pragma unroll
+                for (int m = 0; m < KL; ++m) q[e][m] = q[e][m] - kRoundMagic;
             DDSP_STAGE_END();
 #pragma unroll
-            for (int m = 0; m < KL; ++m) v[m] = __fmaf_rn(-q[m], kTwoPi32, v[m]);     // :42
+            for (int e = 0; e < NS; ++e)
+#pragma unroll
+                for (int m = 0; m < KL; ++m) v[e][m] = __fmaf_rn(-q[e][m], kTwoPi32, v[e][m]);  // :42
             DDSP_STAGE_END();
 #pragma unroll
-            for (int m = 0; m < KL; ++m) v[m] = v[m] * kRevPerRad;
+            for (int e = 0; e < NS; ++e)
+#pragma unroll
+                for (int m = 0; m < KL; ++m) v[e][m] = v[e][m] * kRevPerRad;
             DDSP_STAGE_END();
 #pragma unroll
-            for (int m = 0; m < KL; ++m) v[m] = __builtin_amdgcn_sinf(v[m]);           // v_sin_f32 (revolutions)
+            for (int e = 0; e < NS; ++e)
+#pragma unroll
+                for (int m = 0; m < KL; ++m) v[e][m] = __builtin_amdgcn_sinf(v[e][m]);  // v_sin_f32 (revolutions)
             DDSP_STAGE_END();
 #pragma unroll
-            for (int m = 0; m < KL; ++m) q[m] = __fmaf_rn(w1, st.da[m], st.a0[m]);
-            DDSP_STAGE_END();
-            float s0 = 0.0f, s1 = 0.0f;
+            for (int e = 0; e < NS; ++e)
 #pragma unroll
-            for (int m = 0; m < KL; ++m) {
-                if (m & 1) s1 = __fmaf_rn(q[m], v[m], s1); else s0 = __fmaf_rn(q[m], v[m], s0);  // :48-49
+                for (int m = 0; m < KL; ++m) q[e][m] = __fmaf_rn(w1[e], st.da[m], st.a0[m]);
+            DDSP_STAGE_END();
+            float s0[NS], s1[NS];
+#pragma unroll
+            for (int e = 0; e < NS; ++e) {
+                s0[e] = 0.0f;
+                s1[e] = 0.0f;
+#pragma unroll
+                for (int m = 0; m < KL; ++m) {
+                    if (m & 1) s1[e] = __fmaf_rn(q[e][m], v[e][m], s1[e]); else s0[e] = __fmaf_rn(q[e][m], v[e][m], s0[e]);  // :48-49
+                }
             }
             DDSP_STAGE_END();
-            const float sum = group_sum(s0 + s1, p.logG);
-            const float L = __fmaf_rn(w0, L0, w1 * L1);
-            const float out = L * sum;
-            if (POW2 && MODE == MODE_SYNTH && p.stage_out) {
-                // Stage 32 samples per frame in LDS and flush them as one 128-byte line per group: a 4-byte store per
-                // sample makes the L2 allocate (and fetch) every output line long before it is completely written.
-                float *ys = ystage + (threadIdx.x >> p.logG) * 32;
-                if (j == 0) ys[n & 31] = out;
-                if ((n & 31) == 31) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    const int per = 32 >> p.logG;            // floats per lane: 8, 4 or 2 (G = 4, 8, 16)
-                    float *dst = yframe + (n - 31) + j * per;
-                    if (active) {
-                        if (per == 8) {
-                            reinterpret_cast<float4 *>(dst)[0] = reinterpret_cast<const float4 *>(ys + j * 8)[0];
-                            reinterpret_cast<float4 *>(dst)[1] = reinterpret_cast<const float4 *>(ys + j * 8)[1];
-                        } else if (per == 4) {
-                            reinterpret_cast<float4 *>(dst)[0] = reinterpret_cast<const float4 *>(ys + j * 4)[0];
-                        } else {
-                            reinterpret_cast<float2 *>(dst)[0] = reinterpret_cast<const float2 *>(ys + j * 2)[0];
+            if (POW2 && p.stage_out) {
+                // Output path without cross-lane work in the sample loop: every lane parks L*(its partial sum) in LDS
+                // ([sample & 31][thread], padded rows); every 32 samples the G lanes of a group each sum the G partials
+                // of 32/G samples and store them -- one whole 128-byte line per group (a 4-byte store per sample makes
+                // the L2 allocate, and fetch, each output line long before it is completely written).
+                constexpr int kRow = 256 + 4;
+#pragma unroll
+                for (int e = 0; e < NS; ++e)
+                    ystage[((n + e) & 31) * kRow + threadIdx.x] = __fmaf_rn(w0[e], L0, w1[e] * L1) * (s0[e] + s1[e]);
+                if (((n + NS - 1) & 31) == 31) {
+                    DDSP_WAVE_ORDER();
+                    const int G = 1 << p.logG, per = 32 >> p.logG;   // samples per lane: 8, 4 or 2 (G = 4, 8, 16)
+                    const int gbase = threadIdx.x & ~(G - 1);
+                    float o[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        o[q] = 0.0f;
+                        if (q < per) {
+                            const float *row = ystage + (j * per + q) * kRow + gbase;
+                            for (int g4 = 0; g4 < G; g4 += 4) {
+                                const float4 t4 = *reinterpret_cast<const float4 *>(row + g4);
+                                o[q] += (t4.x + t4.y) + (t4.z + t4.w);
+                            }
                         }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    float *dst = yframe + (n + NS - 32) + j * per;
+                    if (active) {
+                        if (per == 8) {
+                            reinterpret_cast<float4 *>(dst)[0] = make_float4(o[0], o[1], o[2], o[3]);
+                            reinterpret_cast<float4 *>(dst)[1] = make_float4(o[4], o[5], o[6], o[7]);
+                        } else if (per == 4) {
+                            reinterpret_cast<float4 *>(dst)[0] = make_float4(o[0], o[1], o[2], o[3]);
+                        } else {
+                            reinterpret_cast<float2 *>(dst)[0] = make_float2(o[0], o[1]);
+                        }
+                    }
+                    DDSP_WAVE_ORDER();
                 }
-            } else if (j == 0 && active) {
-                yframe[n] = out;
+            } else {
+#pragma unroll
+                for (int e = 0; e < NS; ++e) {
+                    const float sum = group_sum(s0[e] + s1[e], p.logG);
+                    if (j == 0 && active) yframe[n + e] = __fmaf_rn(w0[e], L0, w1[e] * L1) * sum;
+                }
             }
         }
     }
 #undef DDSP_STAGE_END
+#undef DDSP_WAVE_ORDER
 }
 
 // Reference-exact walk: libm fmodf modulo, live offsets (:70), live state and debug phase outputs.
@@ -313,10 +371,10 @@ __global__ void __launch_bounds__(256) osc_supscan_kernel(OscParams p)
 // batch has any silent (masked / zero-amplitude) harmonic, and exactly one of the SKIP / non-SKIP launches runs
 // (the other exits on the flag), so an all-audible batch pays nothing for the extra code.
 template <int K, int VARIANT, bool POW2, bool SKIP>
-__global__ void __launch_bounds__(256) osc_synth_kernel(OscParams p)
+__global__ void __launch_bounds__(256, (SKIP && K <= 13) ? 3 : 1) osc_synth_kernel(OscParams p)
 {
     if (VARIANT == VAR_EXACT && !p.force_exact && *p.redo_flag == 0) return;
-    if (VARIANT == VAR_FAST && POW2 && (p.redo_flag[1] != 0) != SKIP) return;
+    if (VARIANT == VAR_FAST && POW2 && p.R >= 8 && (p.redo_flag[1] != 0) != SKIP) return;
     const int G = 1 << p.logG;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const int j = threadIdx.x & (G - 1);
@@ -370,18 +428,19 @@ __global__ void __launch_bounds__(256) osc_synth_kernel(OscParams p)
                 if (__any(nz)) mlive = m + 1;   // NaN amplitudes (all-masked frame) compare != 0: kept
             }
         }
-#define DDSP_WALK2(KL)                                                                                       \
+#define DDSP_WALK2(KL, NS)                                                                                   \
         do {                                                                                                 \
             load_synth_segment<K>(p, st, b, j, ia, ib, L0, L1);                                              \
-            if (POW2) walk_fast<K, MODE_SYNTH, true, KL>(p, st, b, t, j, active, ia, L0, L1, 0, p.R >> 1);   \
-            else      walk_fast<K, MODE_SYNTH, false, KL>(p, st, b, t, j, active, ia, L0, L1, 0, split);     \
+            if (POW2) walk_fast<K, MODE_SYNTH, true, KL, NS>(p, st, b, t, j, active, ia, L0, L1, 0, p.R >> 1);   \
+            else      walk_fast<K, MODE_SYNTH, false, KL, 1>(p, st, b, t, j, active, ia, L0, L1, 0, split);  \
             load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);                                              \
-            if (POW2) walk_fast<K, MODE_SYNTH, true, KL>(p, st, b, t, j, active, ib, L0, L1, p.R >> 1, p.R); \
-            else      walk_fast<K, MODE_SYNTH, false, KL>(p, st, b, t, j, active, ib, L0, L1, split, p.R);   \
+            if (POW2) walk_fast<K, MODE_SYNTH, true, KL, NS>(p, st, b, t, j, active, ib, L0, L1, p.R >> 1, p.R); \
+            else      walk_fast<K, MODE_SYNTH, false, KL, 1>(p, st, b, t, j, active, ib, L0, L1, split, p.R); \
         } while (0)
-        if (SKIP && mlive <= KQ) DDSP_WALK2(KQ);
-        else if (SKIP && mlive <= KH) DDSP_WALK2(KH);
-        else DDSP_WALK2(K);
+        // short walks advance 4 / 2 samples per iteration (the SKIP kernel is only launched for hop >= 8)
+        if (SKIP && mlive <= KQ) DDSP_WALK2(KQ, 4);
+        else if (SKIP && mlive <= KH) DDSP_WALK2(KH, 2);
+        else DDSP_WALK2(K, 1);
 #undef DDSP_WALK2
     } else {
         float lp[K];
@@ -437,9 +496,9 @@ hipError_t launch_frames(const OscParams &p, hipStream_t s)
     slot = ddsp_prof::begin(ddsp_prof::SYNTH, s);
     if (!live && !p.force_exact) {
         if (p.pow2) {
-            const size_t ylds = p.stage_out ? sizeof(float) * 32 * (256 >> p.logG) : 0;
+            const size_t ylds = p.stage_out ? sizeof(float) * 32 * (256 + 4) : 0;
             hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST, true, false>), dim3(grid), blk, ylds, s, p);
-            hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST, true, true>), dim3(grid), blk, ylds, s, p);
+            if (p.R >= 8) hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST, true, true>), dim3(grid), blk, ylds, s, p);
         } else {
             hipLaunchKernelGGL((osc_synth_kernel<K, VAR_FAST, false, false>), dim3(grid), blk, 0, s, p);
         }
