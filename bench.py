@@ -128,6 +128,10 @@ def main():
     ap.add_argument("--mode", default="synth", choices=["synth", "train"],
                     help="synth: the headline hot path; train: BASELINE.json configs[4] (decoder + MSS loss + Adam, "
                          "batch 32/GPU, flat RCCL gradient all-reduce) -- a secondary figure, not the metric")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (with --backend gloo), instead of cuda:LOCAL_RANK")
     ap.add_argument("--noise", default="device", choices=["device", "resident"],
                     help="uniform draw: in-kernel Philox, or a [B,T,hop] tensor already resident in HBM")
     args = ap.parse_args()
@@ -139,11 +143,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    if args.one_device:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     if args.mode == "train":
         return train_mode(args, rank, world, dist)
