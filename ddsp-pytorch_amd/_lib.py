@@ -73,7 +73,7 @@ EXPORTS = ("ddsp_hip_abi_version", "ddsp_osc_scratch_bytes", "ddsp_osc_forward",
            "ddsp_osc_backward_scratch_bytes", "ddsp_osc_backward", "ddsp_noise_backward",
            "ddsp_osc_set_tiling", "ddsp_noise_set_generic", "ddsp_profile_enable", "ddsp_profile_read")
 
-KERNEL_NAMES = {0: "osc_prep", 1: "osc_frame_totals", 2: "osc_scan", 3: "osc_frame_synth", 4: "noise_frame"}
+KERNEL_NAMES = {1: "osc_frame_totals", 2: "osc_scan", 3: "osc_frame_synth", 4: "noise_frame"}
 
 
 def profile_enable(capacity: int) -> None:

@@ -96,8 +96,9 @@ int ddsp_noise_backward(const float *grad_y, const float *uniform, float *grad_H
  */
 int ddsp_osc_set_tiling(int harmonics_per_lane);
 
-/* Test hook: non-zero forces the generic one-frame-per-workgroup noise kernel (any hop) instead of the
- * batched 64-frames-per-workgroup one (hop % 8 == 0, tile fits LDS).  Same results within rounding. */
+/* Test / tuning hook (process-global): bit 0 forces the generic one-frame-per-workgroup noise kernels (any hop) instead
+ * of the batched ones (hop % 8 == 0, tile fits LDS); (l + 1) << 8 forces 64 >> l frames per workgroup in the batched
+ * forward kernel (l = 0..3); 0 restores the defaults.  Same results within rounding. */
 int ddsp_noise_set_generic(int on);
 
 /*
@@ -105,7 +106,7 @@ int ddsp_noise_set_generic(int on);
  *   ddsp_profile_enable(capacity)  capacity > 0: pre-create that many event pairs and start recording one
  *                                  pair around every kernel launch; capacity <= 0: stop and free them.
  *   ddsp_profile_read(ids, ms, cap) HOST arrays; waits for the recorded events, returns how many records were
- *                                  written (kernel id: 0 prep, 1 frame totals, 2 scan, 3 synth, 4 noise;
+ *                                  written (kernel id: 1 frame totals, 2 superblock scan, 3 synth, 4 noise;
  *                                  elapsed milliseconds) and resets the pool.  Never called from a launch path.
  */
 int ddsp_profile_enable(int capacity);
