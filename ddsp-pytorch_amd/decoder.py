@@ -78,7 +78,10 @@ class Decoder(nn.Module):
     def synthesize(self, ctrl, live: bool = False):
         """`harmonics + noise` for a control dict (decoder.py:129-132 / :141-144)."""
         dry = self.harmonics.live(ctrl) if live else self.harmonics(ctrl)
-        return dry + self.noise(ctrl)
+        if torch.is_grad_enabled() and (dry.requires_grad or ctrl['H'].requires_grad):
+            return dry + self.noise(ctrl)
+        # inference: the noise kernel accumulates straight into the oscillator's buffer (no extra pass over the audio)
+        return self.noise(ctrl, out=dry)
 
     def forward(self, z):
         return self.reverb(self.synthesize(self.controller(z)))

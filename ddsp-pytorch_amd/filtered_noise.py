@@ -85,7 +85,8 @@ class FilteredNoise(nn.Module):
         self.seed = seed
         self._calls = 0
 
-    def forward(self, x, noise=None):
+    def forward(self, x, noise=None, out=None):
+        """`out` (inference only): accumulate the noise into this [B, T*hop] buffer instead of returning a new one."""
         param = x['H']
         B, T, _ = param.shape
         if noise is None and self.rng == 'host':
@@ -99,4 +100,5 @@ class FilteredNoise(nn.Module):
             if not param.is_cuda:
                 raise _lib.DdspHipError("FilteredNoise runs on the GPU only (no CPU fallback): move the controls to cuda")
             return _NoiseFunction.apply(param, noise, self.block_size, self.seed, offset)
-        return noise_forward(param, self.block_size, uniform=noise, seed=self.seed, offset=offset)
+        return noise_forward(param, self.block_size, uniform=noise, seed=self.seed, offset=offset, out=out,
+                             accumulate=out is not None)
