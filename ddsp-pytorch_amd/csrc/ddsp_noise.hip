@@ -120,9 +120,7 @@ __global__ void __launch_bounds__(256) noise_frame_kernel(NoiseParams p)
 //   phase 2  noise tile (injected draw or Philox) -> xs[frame][8 + m] (8 leading zeros = causal padding)
 //   phase 3  truncated convolution, register blocked: a wavefront owns output chunks c and C-1-c
 //            (8 samples each, balanced triangle) of 64 frames; per 8 taps: 6 ds_read_b128, 64 FMAs
-constexpr int kFB = 64;        // frames per workgroup
 constexpr int kNT = 512;       // threads per workgroup
-constexpr int kHS = kFB + 4;   // row stride of the transposed H tile (keeps float4 rows aligned, spreads banks)
 
 __device__ __forceinline__ int kern_stride(int R) { return R + 4; }
 __device__ __forceinline__ int xs_stride(int R) { return R + 12; }
@@ -306,6 +304,7 @@ struct NoiseBwdParams {
     const float *u;      // [B,T,R] the forward's uniform draw (nullable -> Philox from seed/offset, as the forward)
     float *gH;           // [B,T,F]
     int B, T, F, R, S;
+    int lpf_log;         // batched kernel: log2(lanes per frame)
     uint64_t seed, offset;
 };
 
@@ -369,29 +368,30 @@ __global__ void __launch_bounds__(kNT) noise_bwd_batched_kernel(NoiseBwdParams p
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int S = p.S, R = p.R, F = p.F, half = S >> 1;
     const int XS = R + 4, GS = R + 12;
+    const int LPF = 1 << p.lpf_log, FB = 64 >> p.lpf_log, HS = FB + 4;   // lanes per frame, frames per workgroup (as the forward)
     float *ct = smem;                                   // [S] rounded up to a multiple of 4
-    float *xs = ct + ((S + 3) & ~3);                    // [64][XS]
-    float *gs = xs + kFB * XS;                          // [64][GS]  (7+ zeros after the R samples)
-    float *GsT = gs + kFB * GS;                         // [(half+1)][kHS]  folded d/dz, transposed
+    float *xs = ct + ((S + 3) & ~3);                    // [FB][XS]
+    float *gs = xs + FB * XS;                           // [FB][GS]  (7+ zeros after the R samples)
+    float *GsT = gs + FB * GS;                          // [(half+1)][HS]  folded d/dz, transposed
     const int tid = threadIdx.x;
-    const long frame0 = (long)blockIdx.x * kFB;
+    const long frame0 = (long)blockIdx.x * FB;
     const long nframes = (long)p.B * p.T;
-    const int nf = (int)min((long)kFB, nframes - frame0);
+    const int nf = (int)min((long)FB, nframes - frame0);
 
     for (int m = tid; m < S; m += kNT) ct[m] = cospif((float)(2 * m) / (float)S);
-    for (int e = tid; e < (half + 1) * kHS; e += kNT) GsT[e] = 0.0f;
-    for (int e = tid; e < kFB * GS; e += kNT) {
+    for (int e = tid; e < (half + 1) * HS; e += kNT) GsT[e] = 0.0f;
+    for (int e = tid; e < FB * GS; e += kNT) {
         const int f = e / GS, m = e - f * GS;
         gs[e] = (f < nf && m < R) ? p.g[(frame0 + f) * R + m] : 0.0f;
     }
     if (p.u) {
-        for (int e = tid; e < kFB * R; e += kNT) {
+        for (int e = tid; e < FB * R; e += kNT) {
             const int f = e / R, m = e - f * R;
             xs[f * XS + m] = (f < nf) ? p.u[(frame0 + f) * R + m] * 2.0f - 1.0f : 0.0f;
         }
     } else {
         const int quads = R >> 2;
-        for (int e = tid; e < kFB * quads; e += kNT) {
+        for (int e = tid; e < FB * quads; e += kNT) {
             const int f = e / quads, q = e - f * quads;
             const uint64_t ctr = p.offset + (uint64_t)(frame0 + f) * (uint64_t)quads + (uint64_t)q;
             uint32_t r[4];
@@ -408,15 +408,18 @@ __global__ void __launch_bounds__(kNT) noise_bwd_batched_kernel(NoiseBwdParams p
 
     // correlation d/dkern[j] = sum_d x[d] g[j+d], 8 taps x 8 lags per step, chunk c paired with C-1-c
     const int lane = tid & 63, wv = tid >> 6;
-    const int C = R >> 3;
+    const int fr = lane >> p.lpf_log, sub = lane & (LPF - 1);
+    const int C = R >> 3, Q = (C + LPF - 1) >> p.lpf_log;
     const int taps = min(S, R);
-    const float *xrow = xs + lane * XS;
-    const float *grow = gs + lane * GS;
-    for (int pr = wv; 2 * pr < C; pr += kNT / 64) {
+    const float *xrow = xs + fr * XS;
+    const float *grow = gs + fr * GS;
+    for (int pr = wv; 2 * pr < Q; pr += kNT / 64) {
 #pragma unroll 1
         for (int side = 0; side < 2; ++side) {
-            const int c = side ? C - 1 - pr : pr;
-            if (side && c == pr) break;
+            const int qg = side ? Q - 1 - pr : pr;
+            if (side && qg == pr) break;
+            const int c = qg * LPF + sub;
+            if (c >= C) continue;
             const int j0 = c << 3;
             float acc[8];
 #pragma unroll
@@ -445,7 +448,7 @@ __global__ void __launch_bounds__(kNT) noise_bwd_batched_kernel(NoiseBwdParams p
                 if (src < taps && ((src - half) % R + R) % R == j) {
                     const int nfull = (src + half) % S;
                     const int nn = nfull <= half ? nfull : S - nfull;
-                    atomicAdd(&GsT[nn * kHS + lane], acc[u] * (0.5f - 0.5f * ct[src]));
+                    atomicAdd(&GsT[nn * HS + fr], acc[u] * (0.5f - 0.5f * ct[src]));
                 }
             }
         }
@@ -455,22 +458,22 @@ __global__ void __launch_bounds__(kNT) noise_bwd_batched_kernel(NoiseBwdParams p
     // d/dH_k: cosine sums over n, k = 1..S/4 paired with S/2-k, 4 frames per thread
     const float invS = 1.0f / (float)S;
     {   // k = 0 and k = S/2: plain and alternating sums, 8 lanes per frame
-        const int f = tid >> 3, part = tid & 7;
+        const int f = min(tid >> 3, FB - 1), part = tid & 7;
         float e = 0.0f, o = 0.0f;
         for (int n = 1 + part; n < half; n += 8) {
-            const float v = GsT[n * kHS + f];
+            const float v = GsT[n * HS + f];
             if (n & 1) o += v; else e += v;
         }
 #pragma unroll
         for (int m = 1; m < 8; m <<= 1) { e += __shfl_xor(e, m); o += __shfl_xor(o, m); }
-        if (part == 0 && f < nf) {
-            const float v0 = GsT[f], vh = GsT[half * kHS + f];
+        if (part == 0 && (tid >> 3) < FB && f < nf) {
+            const float v0 = GsT[f], vh = GsT[half * HS + f];
             p.gH[(frame0 + f) * F + 0] = invS * (v0 + vh + e + o);
             if (half > 0) p.gH[(frame0 + f) * F + half] = invS * (v0 + ((half & 1) ? -vh : vh) + e - o);
         }
     }
     const int nmain = half / 2;
-    for (int item = tid; item < nmain * (kFB / 4); item += kNT) {
+    for (int item = tid; item < nmain * (FB / 4); item += kNT) {
         const int fq = item / nmain, k = 1 + item - fq * nmain;
         float ev[4] = {0, 0, 0, 0}, ov[4] = {0, 0, 0, 0};
         int idx = 0;
@@ -478,12 +481,12 @@ __global__ void __launch_bounds__(kNT) noise_bwd_batched_kernel(NoiseBwdParams p
             idx += k;
             if (idx >= S) idx -= S;
             const float cc = ct[idx];
-            const float4 v = *reinterpret_cast<const float4 *>(&GsT[n * kHS + 4 * fq]);
+            const float4 v = *reinterpret_cast<const float4 *>(&GsT[n * HS + 4 * fq]);
             if (n & 1) { ov[0] = __fmaf_rn(v.x, cc, ov[0]); ov[1] = __fmaf_rn(v.y, cc, ov[1]); ov[2] = __fmaf_rn(v.z, cc, ov[2]); ov[3] = __fmaf_rn(v.w, cc, ov[3]); }
             else       { ev[0] = __fmaf_rn(v.x, cc, ev[0]); ev[1] = __fmaf_rn(v.y, cc, ev[1]); ev[2] = __fmaf_rn(v.z, cc, ev[2]); ev[3] = __fmaf_rn(v.w, cc, ev[3]); }
         }
         const float4 v0 = *reinterpret_cast<const float4 *>(&GsT[4 * fq]);
-        const float4 vh = *reinterpret_cast<const float4 *>(&GsT[half * kHS + 4 * fq]);
+        const float4 vh = *reinterpret_cast<const float4 *>(&GsT[half * HS + 4 * fq]);
         const float v0v[4] = {v0.x, v0.y, v0.z, v0.w}, vhv[4] = {vh.x, vh.y, vh.z, vh.w};
         const int k2 = half - k;
         const float sg1 = (k & 1) ? -1.0f : 1.0f, sg2 = (k2 & 1) ? -1.0f : 1.0f;
@@ -498,10 +501,18 @@ __global__ void __launch_bounds__(kNT) noise_bwd_batched_kernel(NoiseBwdParams p
     }
 }
 
-size_t bwd_batched_lds_bytes(int F, int R)
+size_t bwd_batched_lds_bytes(int F, int R, int lpf_log)
 {
-    const int S = 2 * (F - 1);
-    return sizeof(float) * (((S + 3) & ~3) + (size_t)kFB * (R + 4) + (size_t)kFB * (R + 12) + (size_t)(S / 2 + 1) * kHS);
+    const int S = 2 * (F - 1), FB = 64 >> lpf_log;
+    return sizeof(float) * (((S + 3) & ~3) + (size_t)FB * (R + 4) + (size_t)FB * (R + 12) + (size_t)(S / 2 + 1) * (FB + 4));
+}
+
+int pick_bwd_lpf_log(int F, int R)
+{
+    for (int limit : {48 * 1024, 80 * 1024, 160 * 1024})
+        for (int l = 0; l <= 3; ++l)
+            if (bwd_batched_lds_bytes(F, R, l) <= (size_t)limit) return l;
+    return -1;
 }
 
 size_t batched_lds_bytes(int F, int R, int lpf_log)
@@ -579,12 +590,15 @@ extern "C" int ddsp_noise_backward(const float *grad_y, const float *uniform, fl
     p.B = B; p.T = T; p.F = F; p.R = hop; p.S = 2 * (F - 1);
     p.seed = seed; p.offset = offset;
     hipStream_t s = (hipStream_t)stream;
-    const size_t blds = bwd_batched_lds_bytes(F, hop);
-    if (!(g_force_generic & 1) && hop % 8 == 0 && blds <= 160 * 1024) {
+    const int lpf_log = pick_bwd_lpf_log(F, hop);
+    p.lpf_log = lpf_log < 0 ? 0 : lpf_log;
+    if (!(g_force_generic & 1) && hop % 8 == 0 && lpf_log >= 0) {
+        const size_t blds = bwd_batched_lds_bytes(F, hop, lpf_log);
         static bool attr_set[64] = {};
         const hipError_t ae = ddsp_allow_big_lds((const void *)noise_bwd_batched_kernel, attr_set);
         if (ae != hipSuccess) return (int)ae;
-        const long blocks = ((long)B * T + kFB - 1) / kFB;
+        const int fb = 64 >> lpf_log;
+        const long blocks = ((long)B * T + fb - 1) / fb;
         hipLaunchKernelGGL(noise_bwd_batched_kernel, dim3((unsigned)blocks), dim3(kNT), blds, s, p);
         return (int)hipGetLastError();
     }

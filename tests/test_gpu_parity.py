@@ -358,3 +358,27 @@ def test_osc_long_clip_extreme_f0_phases_bit_exact():
     assert np.array_equal(np.isfinite(y.cpu().numpy()), ok)
     y2, _, _ = ddsp.osc_forward(dev(f0), dev(c), dev(a), hop, sr)
     assert np.max(np.abs(y2.cpu().numpy()[ok] - ref[ok])) <= TOL_Y
+
+
+@pytest.mark.parametrize("hop,nf,B,T", [(128, 65, 2, 37), (256, 129, 1, 33), (512, 257, 1, 9), (64, 65, 3, 20), (24, 7, 2, 5)])
+def test_noise_grad_batched_equals_generic_and_restatement(hop, nf, B, T):
+    # the batched backward (all tile sizes) against the one-frame-per-workgroup kernel and torch autograd of the restatement
+    from oracle import torch_restatement as tr
+    rng = np.random.default_rng(hop * 7 + nf)
+    Hn = syn.controller_range(rng.standard_normal((B, T, nf), dtype=np.float32))
+    u = rng.random((B, T, hop), dtype=np.float32)
+    gy = rng.standard_normal((B, T * hop)).astype(np.float32)
+    Hr = torch.from_numpy(Hn).requires_grad_()
+    (tr.filtered_noise(Hr, hop, uniform=torch.from_numpy(u)) * torch.from_numpy(gy)).sum().backward()
+    ref = Hr.grad.numpy()
+    L = ddsp._lib.lib()
+    got = {}
+    for generic in (0, 1):
+        L.ddsp_noise_set_generic(generic)
+        try:
+            got[generic] = ddsp.noise_backward(dev(gy), hop, nf, uniform=dev(u)).cpu().numpy()
+        finally:
+            L.ddsp_noise_set_generic(0)
+    scale = max(1.0, float(np.max(np.abs(ref))))
+    assert np.max(np.abs(got[0] - ref)) <= 2e-5 * scale
+    assert np.max(np.abs(got[1] - ref)) <= 2e-5 * scale
