@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(256) osc_totals_kernel(OscParams p)
         st.acc[m] = 0.0;
         st.x0[m] = ok ? w_s[fl * p.H + h] : 0.0f;
         st.x1[m] = ok ? w_s[(fl + 1) * p.H + h] : 0.0f;
-        xc[m] = ok ? w_s[(fl + 2) * p.H + h] : 0.0f;
+        xc[m] = ok ? w_s[(fl + (p.R == 1 ? 1 : 2)) * p.H + h] : 0.0f;   // hop 1: identity upsampling
         lp[m] = (LIVE && ok && b == 0 && p.live_in) ? p.live_in[h] : 0.0f;
     }
     const int split = split_index(t, p.R, p.scale);
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(256, (SKIP && K <= 13) ? 3 : 1) osc_synth_kern
     if (!active) f = nframes - 1;  // keep the lanes alive for the cross-lane sums; their stores are masked
     const int b = (int)(f / p.T);
     const int t = (int)(f - (long)b * p.T);
-    const int ia = max(t - 1, 0), ib = t, ic = min(t + 1, p.T - 1);
+    const int ia = max(t - 1, 0), ib = t, ic = (p.R == 1) ? t : min(t + 1, p.T - 1);  // hop 1: F.interpolate copies (no neighbour term)
     const int sb = t / (256 >> p.logG);
 
     FrameState<K> st;

@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) osc_bwd_kernel(OscParams p, int use_lds)
     if (!active) f = nframes - 1;
     const int b = (int)(f / p.T);
     const int t = (int)(f - (long)b * p.T);
-    const int ia = max(t - 1, 0), ib = t, ic = min(t + 1, p.T - 1);
+    const int ia = max(t - 1, 0), ib = t, ic = (p.R == 1) ? t : min(t + 1, p.T - 1);  // hop 1: F.interpolate copies (no neighbour term)
     const int sb = t / FPB;
 
     FrameState<K> st;

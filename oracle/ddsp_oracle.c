@@ -39,6 +39,7 @@ static inline void upsample_index(int64_t i, float scale, int T, int *i0, int *i
     if (lam > 1.0f) lam = 1.0f;
     *i0 = (int)k;
     *i1 = (int)k + (k < T - 1 ? 1 : 0);
+    if (scale == 1.0f) *i1 = *i0; /* scale_factor 1: ATen copies the input (no neighbour term, so no NaN bleed) */
     *w1 = lam;
     *w0 = 1.0f - lam;
 }

@@ -111,3 +111,38 @@ def test_torch_restatement_noise_bitwise(path):
     torch.manual_seed(int(g["seed"]))
     y2 = tr.filtered_noise(torch.from_numpy(g["H"]), int(g["hop"]))
     assert np.array_equal(bits(y2.numpy()), bits(g["y"]))
+
+
+# ---- C oracle vs torch-op restatement on random shapes (beyond the committed fixtures) ---------------------
+@pytest.mark.parametrize("seed", range(12))
+def test_c_oracle_equals_torch_restatement_random(seed):
+    rng = np.random.default_rng(9000 + seed)
+    B, T = int(rng.integers(1, 4)), int(rng.integers(1, 40))
+    H = int(rng.integers(1, 40))
+    hop = int(rng.choice([1, 2, 3, 5, 8, 16, 31, 64, 100, 128, 257]))
+    sr = int(rng.choice([8000, 16000, 22050, 44100, 48000]))
+    f0 = np.exp(rng.uniform(np.log(5.0), np.log(0.7 * sr), (B, T, 1))).astype(np.float32)
+    if seed % 4 == 0:
+        f0[0, rng.integers(0, T), 0] = 0.0
+    c = rng.uniform(0.0, 2.0, (B, T, H)).astype(np.float32)
+    a = rng.uniform(0.0, 2.0, (B, T, 1)).astype(np.float32)
+    y, d = oracle.osc_forward(f0, c, a, hop, sr, debug=True)
+    yt, pt = tr.oscillator_bank(torch.from_numpy(f0), torch.from_numpy(c), torch.from_numpy(a), hop, sr, return_phases=True)
+    assert np.array_equal(bits(d["phi"]), bits(pt.numpy()))
+    ok = np.isfinite(yt.numpy())
+    assert np.array_equal(np.isfinite(y), ok)
+    if ok.any():
+        assert np.max(np.abs(y[ok] - yt.numpy()[ok])) <= 2e-6
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_c_noise_oracle_equals_torch_restatement_random(seed):
+    rng = np.random.default_rng(9100 + seed)
+    B, T = int(rng.integers(1, 3)), int(rng.integers(1, 9))
+    nf = int(rng.integers(2, 80))
+    hop = int(rng.choice([4, 8, 24, 64, 100, 128, 160, 256]))
+    Hm = rng.uniform(0.0, 2.0, (B, T, nf)).astype(np.float32)
+    u = rng.random((B, T, hop), dtype=np.float32)
+    y = oracle.noise_forward(Hm, u, hop)
+    yt = tr.filtered_noise(torch.from_numpy(Hm), hop, uniform=torch.from_numpy(u)).numpy()
+    assert np.max(np.abs(y - yt)) <= 3e-6 * max(1.0, float(np.max(np.abs(yt))))
