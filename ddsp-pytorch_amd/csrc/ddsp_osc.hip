@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) osc_totals_kernel(OscParams p)
     const float fb = p.f0[rowbase + ib];
 
     FrameState<K> st;
-    float xc[K], lp[K];
+    float xb[K], xc[K], lp[K];
     // Increments of the superblock's frames (+ one halo row on each side) go through LDS so that every
     // (frame, harmonic) costs ONE true division; the three bracketing rows are then read back.
     float *w_s = reinterpret_cast<float *>(tot_s + (size_t)FPB * p.H);  // [(FPB + 2)][H]
@@ -310,8 +310,11 @@ __global__ void __launch_bounds__(256) osc_totals_kernel(OscParams p)
         const bool ok = h < p.H;
         st.acc[m] = 0.0;
         st.x0[m] = ok ? w_s[fl * p.H + h] : 0.0f;
-        st.x1[m] = ok ? w_s[(fl + 1) * p.H + h] : 0.0f;
         xc[m] = ok ? w_s[(fl + (p.R == 1 ? 1 : 2)) * p.H + h] : 0.0f;   // hop 1: identity upsampling
+        // first half of the hop: frames (t-1, t); frame 0 clamps its source index to 0 but still pairs it with frame 1
+        // (weight 0 -- visible only through 0*inf / 0*NaN)
+        st.x1[m] = (t == 0) ? xc[m] : (ok ? w_s[(fl + 1) * p.H + h] : 0.0f);
+        xb[m] = ok ? w_s[(fl + 1) * p.H + h] : 0.0f;
         lp[m] = (LIVE && ok && b == 0 && p.live_in) ? p.live_in[h] : 0.0f;
     }
     const int split = split_index(t, p.R, p.scale);
@@ -323,7 +326,7 @@ __global__ void __launch_bounds__(256) osc_totals_kernel(OscParams p)
         walk_fast<K, MODE_TOTALS, false>(p, st, b, t, j, active, ia, 0.0f, 0.0f, 0, split);
     }
 #pragma unroll
-    for (int m = 0; m < K; ++m) { st.x0[m] = st.x1[m]; st.x1[m] = xc[m]; }
+    for (int m = 0; m < K; ++m) { st.x0[m] = xb[m]; st.x1[m] = xc[m]; }
     if (LIVE) {
         walk_exact<K, MODE_TOTALS>(p, st, lp, b, t, j, active, ib, 0.0f, 0.0f, split, p.R);
     } else if (POW2) {
@@ -430,7 +433,7 @@ __global__ void __launch_bounds__(256, (SKIP && K <= 13) ? 3 : 1) osc_synth_kern
         }
 #define DDSP_WALK2(KL, NS)                                                                                   \
         do {                                                                                                 \
-            load_synth_segment<K>(p, st, b, j, ia, ib, L0, L1);                                              \
+            load_synth_segment<K>(p, st, b, j, ia, t == 0 ? ic : ib, L0, L1);   /* frame 0 clamps to source 0 but keeps neighbour 1 */                                              \
             if (POW2) walk_fast<K, MODE_SYNTH, true, KL, NS>(p, st, b, t, j, active, ia, L0, L1, 0, p.R >> 1);   \
             else      walk_fast<K, MODE_SYNTH, false, KL, 1>(p, st, b, t, j, active, ia, L0, L1, 0, split);  \
             load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);                                              \
@@ -450,12 +453,12 @@ __global__ void __launch_bounds__(256, (SKIP && K <= 13) ? 3 : 1) osc_synth_kern
             lp[m] = (h < p.H && b == 0 && p.live_in) ? p.live_in[h] : 0.0f;
         }
         if (fast && !p.dbg_phi) {
-            load_synth_segment<K>(p, st, b, j, ia, ib, L0, L1);
+            load_synth_segment<K>(p, st, b, j, ia, t == 0 ? ic : ib, L0, L1);   /* frame 0 clamps to source 0 but keeps neighbour 1 */
             walk_exact<K, MODE_SYNTH, true>(p, st, lp, b, t, j, active, ia, L0, L1, 0, split);
             load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);
             walk_exact<K, MODE_SYNTH, true>(p, st, lp, b, t, j, active, ib, L0, L1, split, p.R);
         } else {
-            load_synth_segment<K>(p, st, b, j, ia, ib, L0, L1);
+            load_synth_segment<K>(p, st, b, j, ia, t == 0 ? ic : ib, L0, L1);   /* frame 0 clamps to source 0 but keeps neighbour 1 */
             walk_exact<K, MODE_SYNTH>(p, st, lp, b, t, j, active, ia, L0, L1, 0, split);
             load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);
             walk_exact<K, MODE_SYNTH>(p, st, lp, b, t, j, active, ib, L0, L1, split, p.R);

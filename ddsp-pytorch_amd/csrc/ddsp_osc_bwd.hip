@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) osc_bwd_kernel(OscParams p, int use_lds)
     for (int m = 0; m < K; ++m) pm1[m] = p0[m] = pp1[m] = 0.0f;
     float ga_m1 = 0.0f, ga_0 = 0.0f, ga_p1 = 0.0f;
     float L0, L1;
-    load_synth_segment<K>(p, st, b, j, ia, ib, L0, L1);
+    load_synth_segment<K>(p, st, b, j, ia, t == 0 ? ic : ib, L0, L1);   /* frame 0 clamps to source 0 but keeps neighbour 1 */
     if (fast) walk_bwd<K, false>(p, st, pm1, p0, ga_m1, ga_0, g_lds, g_glb, t, ia, L0, L1, 0, split);
     else      walk_bwd<K, true>(p, st, pm1, p0, ga_m1, ga_0, g_lds, g_glb, t, ia, L0, L1, 0, split);
     load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);

@@ -382,3 +382,27 @@ def test_noise_grad_batched_equals_generic_and_restatement(hop, nf, B, T):
     scale = max(1.0, float(np.max(np.abs(ref))))
     assert np.max(np.abs(got[0] - ref)) <= 2e-5 * scale
     assert np.max(np.abs(got[1] - ref)) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_osc_random_shapes_vs_oracle(seed):
+    # random shapes / hops / rates, f0 up to 0.7*sr (all-masked NaN frames occur), one zero-f0 frame every other seed
+    rng = np.random.default_rng(7000 + seed)
+    B, T = int(rng.integers(1, 5)), int(rng.integers(1, 60))
+    H = int(rng.integers(1, 130))
+    hop = int(rng.choice([1, 2, 3, 5, 8, 16, 31, 64, 100, 128, 256]))
+    sr = int(rng.choice([8000, 16000, 22050, 44100, 48000]))
+    f0 = np.exp(rng.uniform(np.log(5.0), np.log(0.7 * sr), (B, T, 1))).astype(np.float32)
+    if seed % 2 == 0:
+        f0[0, rng.integers(0, T), 0] = 0.0
+    c = rng.uniform(0.0, 2.0, (B, T, H)).astype(np.float32)
+    a = rng.uniform(0.0, 2.0, (B, T, 1)).astype(np.float32)
+    ref, d = oracle.osc_forward(f0, c, a, hop, sr, debug=True)
+    y, _, phi = ddsp.osc_forward(dev(f0), dev(c), dev(a), hop, sr, debug_phases=True)
+    assert np.array_equal(bits(phi.cpu().numpy()), bits(d["phi"]))
+    ok = np.isfinite(ref)
+    for out in (y, ddsp.osc_forward(dev(f0), dev(c), dev(a), hop, sr)[0]):
+        out = out.cpu().numpy()
+        assert np.array_equal(np.isfinite(out), ok)
+        if ok.any():
+            assert np.max(np.abs(out[ok] - ref[ok])) <= TOL_Y
