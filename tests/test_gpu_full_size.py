@@ -112,3 +112,26 @@ def test_hipgraph_capture_and_replay():
     graph.replay()
     torch.cuda.synchronize()
     assert not torch.equal(out, eager)
+
+
+def test_graphed_synth_offline_and_live():
+    class Conf:
+        n_harmonics, sample_rate, hop_length = 60, 16000, 128
+
+    shape = syn.SynthShape("g", 1, 16000, 128, 40, 60, 65)
+    ctl, x = controls(shape, 21, "musical")
+    gs = ddsp.GraphedSynth(Conf, 1, 40, 65, noise_seed=3)
+    y = gs(x).clone()
+    eager, _, _ = ddsp.osc_forward(x["f0"], x["c"], x["a"], 128, 16000)
+    ddsp.noise_forward(x["H"], 128, seed=3, out=eager, accumulate=True)
+    assert torch.equal(y, eager)
+    assert torch.equal(gs(x), eager)                         # replay is deterministic
+    # live: the graph carries the oscillator state exactly like OscillatorBank.live
+    gl = ddsp.GraphedSynth(Conf, 1, 4, 65, live=True, noise_seed=3)
+    osc = ddsp.OscillatorBank(Conf).cuda()
+    for call in range(3):
+        ctl2, x2 = controls(syn.SynthShape("l", 1, 16000, 128, 4, 60, 65), 30 + call, "musical")
+        ref = osc.live(x2)
+        ddsp.noise_forward(x2["H"], 128, seed=3, out=ref, accumulate=True)
+        assert torch.equal(gl(x2), ref)
+        assert torch.equal(gl.state, osc.last_phases.data)
