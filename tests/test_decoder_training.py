@@ -54,7 +54,7 @@ def test_mss_loss_properties():
     y = (x + 0.1 * torch.randn_like(x)).requires_grad_()
     v = loss(y, {"audio": x})
     v.backward()
-    assert float(v) > 0 and torch.isfinite(y.grad).all()
+    assert float(v.detach()) > 0 and torch.isfinite(y.grad).all()
     # one scale against a direct numpy STFT (hann periodic, hop n/4, centre reflect padding, power)
     n = 64
     s = ddsp.training.SpectralLoss(n).power(x[:1, :512]).numpy()[0]
