@@ -154,3 +154,28 @@ def test_decoder_forward_live_and_train_step_gpu():
         out, h2 = dec.forward_live(live, h)
     assert isinstance(out, np.ndarray) and out.shape == (4 * 128,) and h2 is h
     assert dec.harmonics.last_phases.dtype == torch.float32
+
+
+@pytest.mark.gpu
+def test_decoder_end_to_end_matches_reference_fixture():
+    """Drop-in proof for the whole caller: the reference Decoder's weights load strictly into ours and the audio of
+    controller -> harmonics + noise -> reverb matches the reference's CPU output (fixture G13)."""
+    g = load_golden("g13_decoder_end_to_end")
+
+    class C:
+        n_harmonics, n_noise_filters, sample_rate, hop_length = 16, 9, 4000, 64
+        decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 16, 2, 12, 1
+
+    dec = ddsp.Decoder(C)                                        # default noise_rng='host': the reference's RNG semantics
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w__")}
+    dec.load_state_dict(sd, strict=True)
+    dec = dec.cuda()
+    batch = {k: torch.from_numpy(g[k]).cuda() for k in ("normalized_cents", "loudness", "f0")}
+    with torch.no_grad():
+        torch.manual_seed(77)
+        y = dec(batch)
+        torch.manual_seed(78)
+        y_short = dec({k: v[:, :20] for k, v in batch.items()})
+    scale = max(1.0, float(np.max(np.abs(g["y"]))))
+    assert np.max(np.abs(y.cpu().numpy() - g["y"])) <= 2e-5 * scale
+    assert np.max(np.abs(y_short.cpu().numpy() - g["y_short"])) <= 2e-5 * scale

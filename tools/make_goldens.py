@@ -298,9 +298,36 @@ def g12():
          hidden=out["hidden"].numpy(), h0=h0.numpy(), c2=out2["c"].numpy(), hidden2=out2["hidden"].numpy(), h_ret=h_ret.numpy())
 
 
+def g13():
+    # end to end: the reference Decoder.forward (decoder.py:127-135) on the CPU with fixed weights -- controller ->
+    # harmonics + noise -> reverb.  The noise draw comes from the global CPU generator (seeded right before the call).
+    from model.autoencoder.decoder import Decoder as RefDecoder
+
+    class C:
+        n_harmonics, n_noise_filters, sample_rate, hop_length = 16, 9, 4000, 64
+        decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 16, 2, 12, 1
+
+    torch.manual_seed(1313)
+    dec = RefDecoder(C)
+    with torch.no_grad():
+        dec.reverb.wet.fill_(0.5)
+        dec.reverb.decay.fill_(3.0)
+    rng = np.random.default_rng(113)
+    batch = {"normalized_cents": rng.uniform(0, 1, (2, 70, 1)).astype(np.float32),
+             "loudness": rng.uniform(-1, 1, (2, 70, 1)).astype(np.float32),
+             "f0": rng.uniform(60, 300, (2, 70, 1)).astype(np.float32)}
+    tb = {k: t(v) for k, v in batch.items()}
+    torch.manual_seed(77)
+    y = dec(tb)
+    torch.manual_seed(78)
+    y_short = dec({k: v[:, :20] for k, v in tb.items()})       # clip shorter than one second: the reverb crops (reverb.py:34)
+    arrays = {f"w__{k}": v.numpy() for k, v in dec.state_dict().items()}
+    save("g13_decoder_end_to_end", **batch, **arrays, y=y.numpy(), y_short=y_short.numpy())
+
+
 if __name__ == "__main__":
     print("torch", torch.__version__, "threads", torch.get_num_threads())
     only = sys.argv[1:]
-    for fn in (g1, g2_g3_g4, g5, g6, g7, g8, g9, g10, g11, g12):
+    for fn in (g1, g2_g3_g4, g5, g6, g7, g8, g9, g10, g11, g12, g13):
         if not only or fn.__name__ in only:
             fn()
