@@ -225,12 +225,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (phase accumulator f64)", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"batch {shape.batch}/GPU x {world} GPU, {shape.sample_rate} Hz, {shape.n_harmonics} harmonics, "
                                    f"hop {shape.hop}, {shape.frames} frames (4 s), {shape.n_noise_filters} noise bands "
                                    f"(BASELINE.json configs[3] per-GPU shard; metric's batch512)",
                        "f0": args.f0, "noise_rng": args.noise, "parallelism": f"batch-sharded x{world}, no collective",
-                       "step": "OscillatorBank.forward + FilteredNoise.forward accumulated (harmonics + noise)"},
+                       "step": "OscillatorBank.forward + FilteredNoise.forward accumulated (harmonics + noise)",
+                       "arithmetic": "fp32 with an fp64 phase accumulator (torch CPU cumsum semantics)"},
             "samples_per_sec_per_gpu": samples_per_step * args.steps / elapsed / world,
             "roofline": {"bound": "hbm", "kernel": "osc_frame_synth", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
