@@ -1,0 +1,490 @@
+// Recurrent part of the controller's GRU for MI355X (gfx950) -- SURVEY §8f next rows 2-4: the
+// control network of model/autoencoder/decoder.py:66-70,91 is `nn.GRU(2*width, units, layers, batch_first=True)`;
+// its recurrence is 500 strictly sequential steps per 4 s clip, and the stock MIOpen path spends ~110 us per step
+// (forward + backward) in a few dozen tiny launches: 85 % of the whole training step (profiles/r01_train_step*.json).
+//
+// Here the recurrence is ONE persistent launch per direction:
+//   * the input projection gi = x W_ih^T + b_ih for all (b,t) stays a library GEMM (caller side);
+//   * the batch rows are split into NG independent GROUPS (no data ever crosses groups); the hidden units of a group
+//     are split over NW = ceil(Hd/16) workgroups of 256 threads, one per CU, NG*NW <= #CUs.  Workgroup blockIdx.x
+//     belongs to group blockIdx.x % NGpad (NGpad a multiple of 8): with the round-robin dispatch over the 8 XCDs
+//     all members of a group share one XCD's L2 (speed only -- correctness never depends on placement);
+//   * a workgroup keeps its slice of W_hh (16 units x 3 gates x Hd <= 96 KB) in REGISTERS for the whole sequence:
+//     thread (unit ul = tid/16, slice ks = tid%16) holds 3 x Hd/16 weights; per step it multiplies them with the
+//     group's h_{t-1} rows (LDS, conflict-free 16-byte reads, broadcast over the units) and the 16 slices are summed
+//     with four DPP steps inside one DPP row;
+//   * h_t travels between the workgroups of a group as 8-byte {epoch, value} granules (the data is the flag):
+//     relaxed agent-scope stores (sc1, write-through) and relaxed agent-scope polling loads, double-buffered by step
+//     parity; no fence, no separate flag, two workgroup barriers per step.
+// Every spin is bounded by wall-clock time (2 s): on a timeout the workgroup records a status word, poisons its
+// outputs with NaN and leaves, and the others follow, so the grid always drains.
+//
+// Arithmetic is fp32 in ATen's CPU order (RNN.cpp gru cell): r = s(gi_r + gh_r), z = s(gi_z + gh_z),
+// n = tanh(gi_n + r*gh_n), h' = (h - n)*z + n, with gh = W_hh h + b_hh.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "ddsp_hip.h"
+#include "ddsp_internal.h"
+#include "ddsp_osc_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+constexpr int kUnits = 16;        // hidden units per workgroup (threadIdx.x >> 4)
+constexpr int kRowTile = 4;       // batch rows per register tile
+constexpr int kMaxRows = 64;      // batch rows per group (LDS: 64 x 512 x 4 B = 128 KB forward)
+constexpr int kMaxRowsBwd = 16;   // backward stages 3 payloads per row
+constexpr long kSpinTicks = 200000000L;  // 2 s of the 100 MHz wall clock
+
+enum { GRU_OK = 0, GRU_TIMEOUT = 1 };
+
+struct GruParams {
+    const float *gi;      // [B,T,3Hd]  x W_ih^T + b_ih
+    const float *w_hh;    // [3Hd,Hd]
+    const float *b_hh;    // [3Hd] nullable
+    const float *h0;      // [B,Hd] nullable (zeros)
+    float *y;             // [B,T,Hd]   h_t
+    float *hT;            // [B,Hd]
+    float *gates;         // [B,T,3Hd]  r|z|n, nullable (inference) / input of the backward
+    float *hn;            // [B,T,Hd]   W_hn h_{t-1} + b_hn, nullable / input of the backward
+    const float *dy;      // backward: [B,T,Hd]
+    const float *dhT;     // backward: [B,Hd] nullable
+    float *d_gi;          // backward: [B,T,3Hd]
+    float *d_gh;          // backward: [B,T,3Hd]
+    float *dh0;           // backward: [B,Hd]
+    gu64 *xchg;           // granules
+    gu32 *status;         // 0 ok / GRU_TIMEOUT
+    int B, T, Hd;
+    int NG, NGpad, NW, BL;  // groups, padded group count (blockIdx modulus), workgroups per group, rows per group
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ unsigned long long pack_granule(unsigned epoch, float v)
+{
+    return ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v);
+}
+
+// Polls `rows` granule rows of width Hd (row stride HP granules) until every tag equals `epoch`; values go to LDS.
+// A thread owns columns tid and tid + 256 of every row; rows are polled four at a time (eight independent loads
+// in flight per lane), and a batch whose tags all matched is not polled again.  Returns false (wave-uniform) on
+// timeout / abort.
+__device__ __forceinline__ bool sweep_rows(gu64 *src, float *dst, int rows, int Hd, int HP, unsigned epoch, gu32 *status)
+{
+    const long t0 = wall_clock64();
+    const int kc[2] = {(int)threadIdx.x, (int)threadIdx.x + 256};
+    const int nb = (rows + 3) >> 2;                       // <= 16 batches (64 rows forward, 3 x 16 backward)
+    unsigned todo = (1u << nb) - 1u;
+    for (unsigned pass = 0;; ++pass) {
+        for (int bi = 0; bi < nb; ++bi) {
+            if (!((todo >> bi) & 1u)) continue;           // wave-uniform
+            unsigned long long x[4][2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int row = bi * 4 + r;
+                    x[r][c] = (unsigned long long)epoch << 32;
+                    if (row < rows && kc[c] < Hd)
+                        x[r][c] = __hip_atomic_load(src + (size_t)row * HP + kc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            bool ok = true;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int row = bi * 4 + r;
+                    const bool match = (unsigned)(x[r][c] >> 32) == epoch;
+                    ok = ok && match;
+                    if (match && row < rows && kc[c] < Hd) dst[row * HP + kc[c]] = __uint_as_float((unsigned)x[r][c]);
+                }
+            if (__all(ok)) todo &= ~(1u << bi);
+        }
+        if (todo == 0u) return true;
+        if ((pass & 63) == 63) {
+            if (wall_clock64() - t0 > kSpinTicks) return false;
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// ---- forward ------------------------------------------------------------------------------------------------
+template <int KP>
+__global__ void __launch_bounds__(256, 1) gru_fwd_kernel(GruParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float h_s[];  // [BLpad][HP] + 1 word (failure flag)
+    constexpr int HP = 16 * KP;
+    const int group = blockIdx.x % p.NGpad, member = blockIdx.x / p.NGpad;
+    if (group >= p.NG) return;
+    const int row0 = group * p.BL;
+    const int nrows = min(p.BL, p.B - row0);
+    if (nrows <= 0) return;
+    const int BLpad = (p.BL + kRowTile - 1) & ~(kRowTile - 1);
+    int *fail_s = reinterpret_cast<int *>(h_s + BLpad * HP);
+    const int ks = threadIdx.x & 15, ul = threadIdx.x >> 4;
+    const int u = member * kUnits + ul;
+    const int Hd = p.Hd;
+    const bool unit_ok = u < Hd;
+
+    // this thread's slice of W_hh: gate g, unit u, columns k = 64 i + 4 ks + c
+    float w[3][KP];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int e = 0; e < KP; ++e) {
+            const int k = (e >> 2) * 64 + ks * 4 + (e & 3);
+            w[g][e] = (unit_ok && k < Hd) ? p.w_hh[((size_t)g * Hd + u) * Hd + k] : 0.0f;
+        }
+    float bh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bh[g] = (unit_ok && p.b_hh) ? p.b_hh[g * Hd + u] : 0.0f;
+
+    for (int i = threadIdx.x; i < BLpad * HP; i += 256) {
+        const int bl = i / HP, k = i - bl * HP;
+        h_s[i] = (bl < nrows && k < Hd && p.h0) ? p.h0[(size_t)(row0 + bl) * Hd + k] : 0.0f;
+    }
+    if (threadIdx.x == 0) *fail_s = 0;
+    __syncthreads();
+
+    gu64 *xg = p.xchg + (size_t)group * 2 * p.BL * HP;  // [2][BL][HP]
+    const bool gate_lane = unit_ok && ks < kRowTile;
+    const size_t G3 = (size_t)3 * Hd;
+
+    for (int t = 0; t < p.T; ++t) {
+        if (t > 0) {
+            const bool ok = sweep_rows(xg + (size_t)((t - 1) & 1) * p.BL * HP, h_s, nrows, Hd, HP, (unsigned)t, p.status);
+            if (!ok && (threadIdx.x & 63) == 0) *fail_s = 1;
+        }
+        __syncthreads();
+        if (*fail_s) break;
+        for (int bt0 = 0; bt0 < nrows; bt0 += kRowTile) {
+            // the gate lane of (row, unit): its three input-projection terms, loaded ahead of the products
+            const int bl = bt0 + ks;
+            const bool mine = gate_lane && bl < nrows;
+            const size_t bt = ((size_t)(row0 + bl) * p.T + t);
+            float gir = 0.0f, giz = 0.0f, gin = 0.0f;
+            if (mine) {
+                gir = p.gi[bt * G3 + u];
+                giz = p.gi[bt * G3 + Hd + u];
+                gin = p.gi[bt * G3 + 2 * Hd + u];
+            }
+            float acc[kRowTile][3];
+#pragma unroll
+            for (int r = 0; r < kRowTile; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < KP / 4; ++i) {
+#pragma unroll
+                for (int r = 0; r < kRowTile; ++r) {
+                    const float4 hv = *reinterpret_cast<const float4 *>(h_s + (bt0 + r) * HP + i * 64 + ks * 4);
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        acc[r][g] = __fmaf_rn(hv.x, w[g][4 * i + 0], acc[r][g]);
+                        acc[r][g] = __fmaf_rn(hv.y, w[g][4 * i + 1], acc[r][g]);
+                        acc[r][g] = __fmaf_rn(hv.z, w[g][4 * i + 2], acc[r][g]);
+                        acc[r][g] = __fmaf_rn(hv.w, w[g][4 * i + 3], acc[r][g]);
+                    }
+                }
+            }
+            float sr = 0.0f, sz = 0.0f, sn = 0.0f;
+#pragma unroll
+            for (int r = 0; r < kRowTile; ++r) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[r][g] = ddsp_osc::group_sum(acc[r][g], 4);  // the 16 slices = one DPP row
+                if (ks == r) { sr = acc[r][0]; sz = acc[r][1]; sn = acc[r][2]; }
+            }
+            if (mine) {
+                const float hp = h_s[bl * HP + u];
+                const float ghn = sn + bh[2];
+                const float r = sigmoidf_(gir + (sr + bh[0]));
+                const float z = sigmoidf_(giz + (sz + bh[1]));
+                const float n = tanhf(__fmaf_rn(r, ghn, gin));
+                const float hnew = __fmaf_rn(hp - n, z, n);
+                __hip_atomic_store(xg + ((size_t)(t & 1) * p.BL + bl) * HP + u, pack_granule((unsigned)t + 1u, hnew),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p.y[bt * Hd + u] = hnew;
+                if (p.gates) {
+                    p.gates[bt * G3 + u] = r;
+                    p.gates[bt * G3 + Hd + u] = z;
+                    p.gates[bt * G3 + 2 * Hd + u] = n;
+                }
+                if (p.hn) p.hn[bt * Hd + u] = ghn;
+                if (t == p.T - 1) p.hT[(size_t)(row0 + bl) * Hd + u] = hnew;
+            }
+        }
+        __syncthreads();  // h_s is rewritten by the next sweep
+    }
+    if (*fail_s) {
+        if (threadIdx.x == 0) __hip_atomic_store(p.status, (unsigned)GRU_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int bl = ks; bl < nrows; bl += 16)
+            if (unit_ok) {
+                p.hT[(size_t)(row0 + bl) * Hd + u] = __builtin_nanf("");
+                p.y[((size_t)(row0 + bl) * p.T + (p.T - 1)) * Hd + u] = __builtin_nanf("");
+            }
+    }
+}
+
+// ---- backward -----------------------------------------------------------------------------------------------
+// Same decomposition, transposed: the workgroup owns 16 COLUMNS k of dh; thread (k = tid/16, slice us = tid%16)
+// holds W_hh[g*Hd + u'][k] for its source units u' = 64 i + 4 us + c.  Per step (t = T-1 .. 0) the gate lane of
+// (row, k) turns dh_t into the three pre-activation gradients, publishes them, and after the group-wide exchange
+// dh_{t-1}[k] = dh_t[k] z_t[k] + sum_u' (dr W_hr + dz W_hz + d(hn) W_hn)[u',k]  (+ dy_{t-1}[k] at the next step).
+template <int KP>
+__global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float d_s[];  // [BLpad][3][HP] + 1 word
+    constexpr int HP = 16 * KP;
+    const int group = blockIdx.x % p.NGpad, member = blockIdx.x / p.NGpad;
+    if (group >= p.NG) return;
+    const int row0 = group * p.BL;
+    const int nrows = min(p.BL, p.B - row0);
+    if (nrows <= 0) return;
+    const int BLpad = (p.BL + kRowTile - 1) & ~(kRowTile - 1);
+    int *fail_s = reinterpret_cast<int *>(d_s + BLpad * 3 * HP);
+    const int us = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int k = member * kUnits + kl;
+    const int Hd = p.Hd;
+    const bool col_ok = k < Hd;
+
+    float w[3][KP];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int e = 0; e < KP; ++e) {
+            const int uu = (e >> 2) * 64 + us * 4 + (e & 3);
+            w[g][e] = (col_ok && uu < Hd) ? p.w_hh[((size_t)g * Hd + uu) * Hd + k] : 0.0f;
+        }
+    for (int i = threadIdx.x; i < BLpad * 3 * HP; i += 256) d_s[i] = 0.0f;
+    if (threadIdx.x == 0) *fail_s = 0;
+    __syncthreads();
+
+    gu64 *xg = p.xchg + (size_t)group * 2 * p.BL * 3 * HP;  // [2][BL][3][HP]
+    const bool gate_lane = col_ok && us < kRowTile;
+    const size_t G3 = (size_t)3 * Hd;
+    // running dh for the (row, k) pairs this lane is the gate lane of: rows us, us + 4, ... (register array, <= kMaxRowsBwd/4)
+    float carry[kMaxRowsBwd / kRowTile];
+#pragma unroll
+    for (int q = 0; q < kMaxRowsBwd / kRowTile; ++q) {
+        const int bl = q * kRowTile + us;
+        carry[q] = (gate_lane && bl < nrows && p.dhT) ? p.dhT[(size_t)(row0 + bl) * Hd + k] : 0.0f;
+    }
+
+    for (int s = 0; s < p.T; ++s) {
+        const int t = p.T - 1 - s;
+        const unsigned epoch = (unsigned)s + 1u;
+        gu64 *slot = xg + (size_t)(s & 1) * p.BL * 3 * HP;
+        float direct[kMaxRowsBwd / kRowTile];
+        // 1. gate gradients of the owned (row, k) pairs; publish
+#pragma unroll
+        for (int q = 0; q < kMaxRowsBwd / kRowTile; ++q) {
+            const int bl = q * kRowTile + us;
+            direct[q] = 0.0f;
+            if (gate_lane && bl < nrows) {
+                const size_t bt = (size_t)(row0 + bl) * p.T + t;
+                const float dh = p.dy[bt * Hd + k] + carry[q];
+                const float r = p.gates[bt * G3 + k], z = p.gates[bt * G3 + Hd + k], n = p.gates[bt * G3 + 2 * Hd + k];
+                const float ghn = p.hn[bt * Hd + k];
+                const float hp = (t > 0) ? p.y[(bt - 1) * Hd + k] : (p.h0 ? p.h0[(size_t)(row0 + bl) * Hd + k] : 0.0f);
+                const float dz = dh * (hp - n);
+                const float dn = dh * (1.0f - z);
+                const float dn_pre = dn * (1.0f - n * n);
+                const float dr_pre = (dn_pre * ghn) * (r * (1.0f - r));
+                const float dz_pre = dz * (z * (1.0f - z));
+                const float dhn = dn_pre * r;
+                direct[q] = dh * z;
+                gu64 *gdst = slot + (size_t)bl * 3 * HP + k;
+                __hip_atomic_store(gdst, pack_granule(epoch, dr_pre), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gdst + HP, pack_granule(epoch, dz_pre), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gdst + 2 * HP, pack_granule(epoch, dhn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p.d_gi[bt * G3 + k] = dr_pre;
+                p.d_gi[bt * G3 + Hd + k] = dz_pre;
+                p.d_gi[bt * G3 + 2 * Hd + k] = dn_pre;
+                p.d_gh[bt * G3 + k] = dr_pre;
+                p.d_gh[bt * G3 + Hd + k] = dz_pre;
+                p.d_gh[bt * G3 + 2 * Hd + k] = dhn;
+            }
+        }
+        // 2. the group's gate gradients -> LDS  (rows of 3 payloads: treated as 3*nrows rows of width Hd)
+        {
+            const bool ok = sweep_rows(slot, d_s, 3 * nrows, Hd, HP, epoch, p.status);
+            if (!ok && (threadIdx.x & 63) == 0) *fail_s = 1;
+        }
+        __syncthreads();
+        if (*fail_s) break;
+        // 3. dh_{t-1}[k] = direct + sum over source units
+#pragma unroll
+        for (int q = 0; q < kMaxRowsBwd / kRowTile; ++q) {
+            const int bt0 = q * kRowTile;
+            if (bt0 < nrows) {
+                float acc[kRowTile];
+#pragma unroll
+                for (int r = 0; r < kRowTile; ++r) acc[r] = 0.0f;
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int i = 0; i < KP / 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < kRowTile; ++r) {
+                            const float4 dv = *reinterpret_cast<const float4 *>(d_s + ((bt0 + r) * 3 + g) * HP + i * 64 + us * 4);
+                            acc[r] = __fmaf_rn(dv.x, w[g][4 * i + 0], acc[r]);
+                            acc[r] = __fmaf_rn(dv.y, w[g][4 * i + 1], acc[r]);
+                            acc[r] = __fmaf_rn(dv.z, w[g][4 * i + 2], acc[r]);
+                            acc[r] = __fmaf_rn(dv.w, w[g][4 * i + 3], acc[r]);
+                        }
+                float mine = 0.0f;
+#pragma unroll
+                for (int r = 0; r < kRowTile; ++r) {
+                    acc[r] = ddsp_osc::group_sum(acc[r], 4);
+                    if (us == r) mine = acc[r];
+                }
+                carry[q] = direct[q] + mine;
+            }
+        }
+        __syncthreads();  // d_s is rewritten by the next sweep
+    }
+    if (*fail_s) {
+        if (threadIdx.x == 0) __hip_atomic_store(p.status, (unsigned)GRU_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 0; q < kMaxRowsBwd / kRowTile; ++q) carry[q] = __builtin_nanf("");
+    }
+#pragma unroll
+    for (int q = 0; q < kMaxRowsBwd / kRowTile; ++q) {
+        const int bl = q * kRowTile + us;
+        if (gate_lane && bl < nrows) p.dh0[(size_t)(row0 + bl) * Hd + k] = carry[q];
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------
+struct GruPlan { int KP, HP, NW, NG, NGpad, BL; };
+
+// Groups / rows per group for a [B, Hd] problem on a device with `cus` compute units; false if it does not fit.
+bool plan_gru(int B, int Hd, int cus, int max_rows, GruPlan *pl)
+{
+    if (Hd > 512) return false;
+    pl->KP = Hd <= 64 ? 4 : (Hd <= 128 ? 8 : (Hd <= 256 ? 16 : 32));
+    pl->HP = 16 * pl->KP;
+    pl->NW = (Hd + kUnits - 1) / kUnits;
+    int slots = cus / pl->NW;          // groups that can be co-resident, one workgroup per CU
+    slots -= slots % 8;                // blockIdx modulus is a multiple of 8 (XCD alignment)
+    if (slots < 8) return false;
+    pl->NG = B < slots ? B : slots;
+    pl->BL = (B + pl->NG - 1) / pl->NG;
+    pl->NG = (B + pl->BL - 1) / pl->BL;
+    pl->NGpad = (pl->NG + 7) & ~7;
+    return pl->BL <= max_rows;
+}
+
+int device_cus(int *cus)
+{
+    static int cached[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (!cached[dev & 63]) {
+        int n = 0;
+        e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return (int)e;
+        cached[dev & 63] = n;
+    }
+    *cus = cached[dev & 63];
+    return 0;
+}
+
+size_t xchg_bytes(const GruPlan &pl, int payloads) { return (size_t)pl.NG * 2 * pl.BL * payloads * pl.HP * sizeof(unsigned long long); }
+
+template <int KP>
+hipError_t launch_gru(const GruParams &p, bool backward, size_t lds, hipStream_t s)
+{
+    static bool attr_f[64] = {}, attr_b[64] = {};
+    const void *fn = backward ? (const void *)gru_bwd_kernel<KP> : (const void *)gru_fwd_kernel<KP>;
+    const hipError_t e = ddsp_allow_big_lds(fn, backward ? attr_b : attr_f);
+    if (e != hipSuccess) return e;
+    const dim3 grid((unsigned)(p.NGpad * p.NW)), blk(256);
+    if (backward) hipLaunchKernelGGL(gru_bwd_kernel<KP>, grid, blk, lds, s, p);
+    else hipLaunchKernelGGL(gru_fwd_kernel<KP>, grid, blk, lds, s, p);
+    return hipGetLastError();
+}
+
+int run_gru(GruParams &p, void *scratch, bool backward, hipStream_t s)
+{
+    int cus = 0;
+    const int rc = device_cus(&cus);
+    if (rc) return rc;
+    GruPlan pl;
+    if (!plan_gru(p.B, p.Hd, cus, backward ? kMaxRowsBwd : kMaxRows, &pl)) return DDSP_ERANGE;
+    p.NG = pl.NG; p.NGpad = pl.NGpad; p.NW = pl.NW; p.BL = pl.BL;
+    const int payloads = backward ? 3 : 1;
+    // scratch: [status: 256 B][granules]; every polled word is zeroed before EVERY launch (epochs restart at 1)
+    p.status = (gu32 *)scratch;
+    p.xchg = (gu64 *)((char *)scratch + 256);
+    hipError_t e = hipMemsetAsync(scratch, 0, 256 + xchg_bytes(pl, payloads), s);
+    if (e != hipSuccess) return (int)e;
+    const int BLpad = (pl.BL + kRowTile - 1) & ~(kRowTile - 1);
+    const size_t lds = sizeof(float) * ((size_t)BLpad * payloads * pl.HP + 4);
+    switch (pl.KP) {
+        case 4: e = launch_gru<4>(p, backward, lds, s); break;
+        case 8: e = launch_gru<8>(p, backward, lds, s); break;
+        case 16: e = launch_gru<16>(p, backward, lds, s); break;
+        default: e = launch_gru<32>(p, backward, lds, s); break;
+    }
+    return (int)e;
+}
+
+}  // namespace
+
+extern "C" size_t ddsp_gru_scratch_bytes(int B, int Hd)
+{
+    if (B <= 0 || Hd <= 0 || Hd > 512) return 0;
+    // upper bound over every plan: (B + one group's padding) rows x 3 payloads x 2 parities x 512 granules
+    return 256 + (size_t)(B + kMaxRows) * 2 * 3 * 512 * sizeof(unsigned long long);
+}
+
+extern "C" int ddsp_gru_max_batch(int Hd, int backward)
+{
+    int cus = 0;
+    if (device_cus(&cus)) return 0;
+    GruPlan pl;
+    if (!plan_gru(1, Hd, cus, 1, &pl)) return 0;
+    int slots = cus / pl.NW;
+    slots -= slots % 8;
+    return slots * (backward ? kMaxRowsBwd : kMaxRows);
+}
+
+extern "C" int ddsp_gru_forward(const float *gi, const float *w_hh, const float *b_hh, const float *h0, float *y, float *hT,
+                                float *gates, float *hn, void *scratch, int B, int T, int Hd, void *stream)
+{
+    if (B == 0) return 0;
+    if (!gi || !w_hh || !y || !hT || !scratch || B < 0 || T <= 0 || Hd <= 0) return DDSP_EINVAL;
+    if ((gates == nullptr) != (hn == nullptr)) return DDSP_EINVAL;
+    GruParams p = {};
+    p.gi = gi; p.w_hh = w_hh; p.b_hh = b_hh; p.h0 = h0; p.y = y; p.hT = hT; p.gates = gates; p.hn = hn;
+    p.B = B; p.T = T; p.Hd = Hd;
+    return run_gru(p, scratch, false, (hipStream_t)stream);
+}
+
+extern "C" int ddsp_gru_backward(const float *dy, const float *dhT, const float *w_hh, const float *h0, const float *y,
+                                 const float *gates, const float *hn, float *d_gi, float *d_gh, float *dh0, void *scratch,
+                                 int B, int T, int Hd, void *stream)
+{
+    if (B == 0) return 0;
+    if (!dy || !w_hh || !y || !gates || !hn || !d_gi || !d_gh || !dh0 || !scratch || B < 0 || T <= 0 || Hd <= 0) return DDSP_EINVAL;
+    GruParams p = {};
+    p.dy = dy; p.dhT = dhT; p.w_hh = w_hh; p.h0 = h0; p.y = const_cast<float *>(y);
+    p.gates = const_cast<float *>(gates); p.hn = const_cast<float *>(hn);
+    p.d_gi = d_gi; p.d_gh = d_gh; p.dh0 = dh0;
+    p.B = B; p.T = T; p.Hd = Hd;
+    return run_gru(p, scratch, true, (hipStream_t)stream);
+}
+
+extern "C" int ddsp_gru_status(const void *scratch, int *status_host)
+{
+    if (!scratch || !status_host) return DDSP_EINVAL;
+    unsigned v = 0;
+    const hipError_t e = hipMemcpy(&v, scratch, sizeof(v), hipMemcpyDeviceToHost);
+    *status_host = (int)v;
+    return (int)e;
+}

@@ -1,6 +1,7 @@
 """Callers of the hot path: the control network and the `Decoder`
-wiring of model/autoencoder/decoder.py:41-147, restated with stock torch.nn layers (rocBLAS / MIOpen do
-the dense work; nothing hand-written here) around the HIP synth modules of this package.
+wiring of model/autoencoder/decoder.py:41-147, restated with stock torch.nn layers (rocBLAS does the dense
+work) around the HIP synth modules of this package; the GRU's recurrence runs on the persistent HIP kernel of
+`gru.py` (MIOpen's per-step launches were 85 % of the training step).
 
 Sub-module and parameter names follow the reference so that its checkpoints load with strict=True
 (`rt/utils.py:7-24` strips the `model.` prefix, `rt/synth.py:17` loads into `zak.decoder`):
@@ -13,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from .filtered_noise import FilteredNoise
+from .gru import GRU
 from .harmonic_oscillator import OscillatorBank
 from .reverb import Reverb
 
@@ -46,7 +48,7 @@ class Controller(nn.Module):
         width, depth = conf.decoder_mlp_units, conf.decoder_mlp_layers
         self.mlp_f0 = _dense_stack(1, width, depth)
         self.mlp_loudness = _dense_stack(1, width, depth)
-        self.gru = nn.GRU(2 * width, conf.decoder_gru_units, conf.decoder_gru_layers, batch_first=True)
+        self.gru = GRU(2 * width, conf.decoder_gru_units, conf.decoder_gru_layers, batch_first=True)
         self.mlp_gru = _dense_stack(conf.decoder_gru_units + 2 * width, width, depth)
         self.dense_harmonic = nn.Linear(width, conf.n_harmonics)
         self.dense_loudness = nn.Linear(width, 1)

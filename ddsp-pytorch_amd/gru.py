@@ -1,0 +1,140 @@
+"""`GRU`: `torch.nn.GRU` with the recurrence on one persistent HIP launch (include/ddsp_hip.h: ddsp_gru_*).
+
+The reference's control network runs `nn.GRU(2*width, units, layers, batch_first=True)` over the whole clip
+(model/autoencoder/decoder.py:66-70, :91) and over one callback's frames with a carried state in the live path
+(:91 via `forward_live` :139-147).  This class IS an `nn.GRU` (same parameters `weight_ih_l0 / weight_hh_l0 /
+bias_ih_l0 / bias_hh_l0`, so the reference's checkpoints load unchanged); for CUDA inputs of a single-layer,
+unidirectional GRU with hidden size <= 512 it computes
+
+    gi = x W_ih^T + b_ih                       one library GEMM (differentiated by autograd as usual)
+    y, h_T = recurrence(gi, W_hh, b_hh, h_0)   csrc/ddsp_gru.hip, forward and backward
+
+instead of MIOpen's per-time-step launches.  Other configurations, and CPU tensors, use the stock `nn.GRU`
+implementation (the controller is a stock-layer caller of the hot path, not part of it).  On a CUDA input a missing
+library raises `DdspHipError` -- there is no silent fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def gru_forward(gi, w_hh, b_hh, h0, save: bool):
+    """Raw launcher of ddsp_gru_forward. gi [B,T,3Hd] -> (y [B,T,Hd], hT [B,Hd], gates | None, hn | None)."""
+    B, T, G3 = gi.shape
+    Hd = G3 // 3
+    L = _lib.lib()
+    y = torch.empty((B, T, Hd), device=gi.device, dtype=torch.float32)
+    hT = torch.empty((B, Hd), device=gi.device, dtype=torch.float32)
+    gates = torch.empty((B, T, G3), device=gi.device, dtype=torch.float32) if save else None
+    hn = torch.empty((B, T, Hd), device=gi.device, dtype=torch.float32) if save else None
+    if B == 0:
+        return y, hT, gates, hn
+    with torch.cuda.device(gi.device):
+        cap = L.ddsp_gru_max_batch(Hd, 0)
+        if cap <= 0:
+            raise _lib.DdspHipError(f"ddsp_gru_forward: hidden size {Hd} is not supported")
+        stream = torch.cuda.current_stream().cuda_stream
+        for lo in range(0, B, cap):                      # rows are independent: larger batches go in slices
+            hi = min(B, lo + cap)
+            scratch = torch.empty(L.ddsp_gru_scratch_bytes(hi - lo, Hd), device=gi.device, dtype=torch.uint8)
+            rc = L.ddsp_gru_forward(gi[lo:hi].data_ptr(), w_hh.data_ptr(), _ptr(b_hh), _ptr(h0[lo:hi]) if h0 is not None else None,
+                                    y[lo:hi].data_ptr(), hT[lo:hi].data_ptr(), _ptr(gates[lo:hi]) if save else None,
+                                    _ptr(hn[lo:hi]) if save else None, scratch.data_ptr(), hi - lo, T, Hd, stream)
+            _lib.check(rc, "ddsp_gru_forward")
+            gru_forward.last_scratch = scratch
+    return y, hT, gates, hn
+
+
+def gru_backward(dy, dhT, w_hh, h0, y, gates, hn):
+    """Raw launcher of ddsp_gru_backward -> (d_gi [B,T,3Hd], d_gh [B,T,3Hd], dh0 [B,Hd])."""
+    B, T, Hd = y.shape
+    L = _lib.lib()
+    d_gi = torch.empty_like(gates)
+    d_gh = torch.empty_like(gates)
+    dh0 = torch.empty((B, Hd), device=y.device, dtype=torch.float32)
+    with torch.cuda.device(y.device):
+        cap = L.ddsp_gru_max_batch(Hd, 1)
+        stream = torch.cuda.current_stream().cuda_stream
+        for lo in range(0, B, cap):
+            hi = min(B, lo + cap)
+            scratch = torch.empty(L.ddsp_gru_scratch_bytes(hi - lo, Hd), device=y.device, dtype=torch.uint8)
+            rc = L.ddsp_gru_backward(dy[lo:hi].data_ptr(), _ptr(dhT[lo:hi]) if dhT is not None else None, w_hh.data_ptr(),
+                                     _ptr(h0[lo:hi]) if h0 is not None else None, y[lo:hi].data_ptr(), gates[lo:hi].data_ptr(),
+                                     hn[lo:hi].data_ptr(), d_gi[lo:hi].data_ptr(), d_gh[lo:hi].data_ptr(), dh0[lo:hi].data_ptr(),
+                                     scratch.data_ptr(), hi - lo, T, Hd, stream)
+            _lib.check(rc, "ddsp_gru_backward")
+            gru_backward.last_scratch = scratch
+    return d_gi, d_gh, dh0
+
+
+def gru_status(scratch) -> int:
+    """0, or 1 if a workgroup of the launch that used `scratch` timed out waiting for its peers (synchronises)."""
+    out = ctypes.c_int(0)
+    _lib.check(_lib.lib().ddsp_gru_status(scratch.data_ptr(), ctypes.byref(out)), "ddsp_gru_status")
+    return out.value
+
+
+class _Recurrence(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gi, w_hh, b_hh, h0):
+        gi = gi.contiguous().float()
+        w = w_hh.detach().contiguous().float()
+        b = None if b_hh is None else b_hh.detach().contiguous().float()
+        h = None if h0 is None else h0.detach().contiguous().float()
+        need = any(ctx.needs_input_grad)
+        y, hT, gates, hn = gru_forward(gi.detach(), w, b, h, save=need)
+        if need:
+            ctx.save_for_backward(w, h, y, gates, hn)
+            ctx.has_bias = b is not None
+        return y, hT
+
+    @staticmethod
+    def backward(ctx, dy, dhT):
+        w, h0, y, gates, hn = ctx.saved_tensors
+        B, T, Hd = y.shape
+        dy = torch.zeros_like(y) if dy is None else dy.contiguous().float()
+        dhT = None if dhT is None else dhT.contiguous().float()
+        d_gi, d_gh, dh0 = gru_backward(dy, dhT, w, h0, y, gates, hn)
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            first = h0 if h0 is not None else torch.zeros((B, Hd), device=y.device, dtype=y.dtype)
+            h_prev = torch.cat((first.unsqueeze(1), y[:, :-1]), dim=1)          # h_{t-1} for every step
+            dw = d_gh.reshape(B * T, 3 * Hd).t() @ h_prev.reshape(B * T, Hd)  # library GEMM [3Hd, BT] x [BT, Hd]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = d_gh.sum(dim=(0, 1))
+        return d_gi, dw, db, (dh0 if ctx.needs_input_grad[3] else None)
+
+
+class GRU(nn.GRU):
+    """Drop-in `nn.GRU`; see the module docstring for when the HIP recurrence runs."""
+
+    def _hip_eligible(self, x: torch.Tensor) -> bool:
+        return (x.is_cuda and x.dim() == 3 and self.num_layers == 1 and not self.bidirectional and self.proj_size == 0
+                and self.hidden_size <= 512 and x.dtype == torch.float32)
+
+    def forward(self, input, hx=None):  # noqa: A002 (torch's argument name)
+        if not self._hip_eligible(input):
+            return super().forward(input, hx)
+        x = input if self.batch_first else input.transpose(0, 1)
+        b_ih = getattr(self, "bias_ih_l0", None) if self.bias else None
+        b_hh = getattr(self, "bias_hh_l0", None) if self.bias else None
+        gi = F.linear(x, self.weight_ih_l0, b_ih)
+        h0 = None
+        if hx is not None:
+            if hx.dim() != 3 or hx.shape[0] != 1 or hx.shape[1] != x.shape[0] or hx.shape[2] != self.hidden_size:
+                raise RuntimeError(f"Expected hidden size (1, {x.shape[0]}, {self.hidden_size}), got {list(hx.shape)}")
+            h0 = hx[0]
+        y, hT = _Recurrence.apply(gi, self.weight_hh_l0, b_hh, h0)
+        if not self.batch_first:
+            y = y.transpose(0, 1)
+        return y, hT.unsqueeze(0)

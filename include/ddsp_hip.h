@@ -112,6 +112,34 @@ int ddsp_noise_set_generic(int on);
 int ddsp_profile_enable(int capacity);
 int ddsp_profile_read(int *kernel_ids, float *ms, int cap);
 
+/*
+ * Recurrence of the control network's GRU (model/autoencoder/decoder.py:66-70 builds
+ * nn.GRU(2*width, units, layers, batch_first=True); :91 runs it).  One persistent launch
+ * per direction replaces the ~20 library launches per time step of the stock path; the input projection
+ * gi = x W_ih^T + b_ih (and the weight-gradient GEMMs) stay library GEMMs on the caller's side.
+ * Single layer, unidirectional, gate order r|z|n as in torch; fp32; Hd <= 512.
+ *
+ *   ddsp_gru_scratch_bytes(B, Hd)   device scratch for either direction (status word + hand-off granules)
+ *   ddsp_gru_max_batch(Hd, backward) rows one launch accepts on the current device (callers split larger
+ *                                   batches: rows are independent); 0 if Hd is unsupported
+ *   ddsp_gru_forward   gi [B,T,3Hd], w_hh [3Hd,Hd], b_hh [3Hd] (nullable), h0 [B,Hd] (nullable = zeros)
+ *                      -> y [B,T,Hd] (all h_t), hT [B,Hd]; gates [B,T,3Hd] and hn [B,T,Hd] (both nullable
+ *                      together) receive r|z|n and W_hn h_{t-1} + b_hn for the backward
+ *   ddsp_gru_backward  dy [B,T,Hd], dhT [B,Hd] (nullable) + the forward's tensors
+ *                      -> d_gi [B,T,3Hd] (gradient of gi), d_gh [B,T,3Hd] (gradient of W_hh h + b_hh), dh0 [B,Hd]
+ *   ddsp_gru_status    HOST int*: 0, or 1 if a workgroup gave up waiting for its peers (outputs are then NaN);
+ *                      synchronous copy, tests / diagnostics only
+ * The grid is sized to be co-resident (one workgroup per CU); every wait inside is bounded (2 s).
+ */
+size_t ddsp_gru_scratch_bytes(int B, int Hd);
+int ddsp_gru_max_batch(int Hd, int backward);
+int ddsp_gru_forward(const float *gi, const float *w_hh, const float *b_hh, const float *h0, float *y, float *hT,
+                     float *gates, float *hn, void *scratch, int B, int T, int Hd, void *stream);
+int ddsp_gru_backward(const float *dy, const float *dhT, const float *w_hh, const float *h0, const float *y,
+                      const float *gates, const float *hn, float *d_gi, float *d_gh, float *dh0, void *scratch,
+                      int B, int T, int Hd, void *stream);
+int ddsp_gru_status(const void *scratch, int *status_host);
+
 #ifdef __cplusplus
 }
 #endif
