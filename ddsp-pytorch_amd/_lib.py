@@ -71,6 +71,8 @@ def lib():
     L.ddsp_gru_forward.argtypes = [vp] * 9 + [i32] * 3 + [vp]
     L.ddsp_gru_backward.restype = i32
     L.ddsp_gru_backward.argtypes = [vp] * 11 + [i32] * 3 + [vp]
+    L.ddsp_gru_set_mode.restype = i32
+    L.ddsp_gru_set_mode.argtypes = [i32]
     L.ddsp_gru_status.restype = i32
     L.ddsp_gru_status.argtypes = [vp, ctypes.POINTER(i32)]
     if L.ddsp_hip_abi_version() != ABI_VERSION:
@@ -82,7 +84,7 @@ def lib():
 EXPORTS = ("ddsp_hip_abi_version", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_noise_forward",
            "ddsp_osc_backward_scratch_bytes", "ddsp_osc_backward", "ddsp_noise_backward",
            "ddsp_osc_set_tiling", "ddsp_noise_set_generic", "ddsp_profile_enable", "ddsp_profile_read",
-           "ddsp_gru_scratch_bytes", "ddsp_gru_max_batch", "ddsp_gru_forward", "ddsp_gru_backward", "ddsp_gru_status")
+           "ddsp_gru_scratch_bytes", "ddsp_gru_max_batch", "ddsp_gru_forward", "ddsp_gru_backward", "ddsp_gru_status", "ddsp_gru_set_mode")
 
 KERNEL_NAMES = {1: "osc_frame_totals", 2: "osc_scan", 3: "osc_frame_synth", 4: "noise_frame"}
 

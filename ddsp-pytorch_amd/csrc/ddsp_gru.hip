@@ -1,5 +1,5 @@
 // Recurrent part of the controller's GRU for MI355X (gfx950) -- SURVEY §8f next rows 2-4: the
-// control network of model/autoencoder/decoder.py:66-70,91 is `nn.GRU(2*width, units, layers, batch_first=True)`;
+// control network of model/autoencoder/decoder.py:60-65,91 is `nn.GRU(2*width, units, layers, batch_first=True)`;
 // its recurrence is 500 strictly sequential steps per 4 s clip, and the stock MIOpen path spends ~110 us per step
 // (forward + backward) in a few dozen tiny launches: 85 % of the whole training step (profiles/r01_train_step*.json).
 //
@@ -8,7 +8,8 @@
 //   * the batch rows are split into NG independent GROUPS (no data ever crosses groups); the hidden units of a group
 //     are split over NW = ceil(Hd/16) workgroups of 256 threads, one per CU, NG*NW <= #CUs.  Workgroup blockIdx.x
 //     belongs to group blockIdx.x % NGpad (NGpad a multiple of 8): with the round-robin dispatch over the 8 XCDs
-//     all members of a group share one XCD's L2 (speed only -- correctness never depends on placement);
+//     all members of a group share one XCD (speed only -- every hand-off is agent scope, correct for any placement;
+//     the test hook ddsp_gru_set_mode(1) deals each group over all XCDs and the results stay bitwise the same);
 //   * a workgroup keeps its slice of W_hh (16 units x 3 gates x Hd <= 96 KB) in REGISTERS for the whole sequence:
 //     thread (unit ul = tid/16, slice ks = tid%16) holds 3 x Hd/16 weights; per step it multiplies them with the
 //     group's h_{t-1} rows (LDS, conflict-free 16-byte reads, broadcast over the units) and the 16 slices are summed
@@ -62,7 +63,9 @@ struct GruParams {
     int NG, NGpad, NW, BL;  // groups, padded group count (blockIdx modulus), workgroups per group, rows per group
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities on the hardware exp2 / rcp (1 ulp each): |error| <= 2e-7, on the critical path of every step.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 __device__ __forceinline__ unsigned long long pack_granule(unsigned epoch, float v)
 {
@@ -70,34 +73,35 @@ __device__ __forceinline__ unsigned long long pack_granule(unsigned epoch, float
 }
 
 // Polls `rows` granule rows of width Hd (row stride HP granules) until every tag equals `epoch`; values go to LDS.
-// A thread owns columns tid and tid + 256 of every row; rows are polled four at a time (eight independent loads
-// in flight per lane), and a batch whose tags all matched is not polled again.  Returns false (wave-uniform) on
+// A thread owns columns tid and tid + 256 of every row; rows are polled RB at a time (2 RB independent loads in
+// flight per lane), and a batch whose tags all matched is not polled again.  Returns false (wave-uniform) on
 // timeout / abort.
+template <int RB>
 __device__ __forceinline__ bool sweep_rows(gu64 *src, float *dst, int rows, int Hd, int HP, unsigned epoch, gu32 *status)
 {
     const long t0 = wall_clock64();
     const int kc[2] = {(int)threadIdx.x, (int)threadIdx.x + 256};
-    const int nb = (rows + 3) >> 2;                       // <= 16 batches (64 rows forward, 3 x 16 backward)
+    const int nb = (rows + RB - 1) / RB;                  // <= 16 batches
     unsigned todo = (1u << nb) - 1u;
     for (unsigned pass = 0;; ++pass) {
         for (int bi = 0; bi < nb; ++bi) {
             if (!((todo >> bi) & 1u)) continue;           // wave-uniform
-            unsigned long long x[4][2];
+            unsigned long long x[RB][2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < RB; ++r)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const int row = bi * 4 + r;
+                    const int row = bi * RB + r;
                     x[r][c] = (unsigned long long)epoch << 32;
                     if (row < rows && kc[c] < Hd)
                         x[r][c] = __hip_atomic_load(src + (size_t)row * HP + kc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             bool ok = true;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < RB; ++r)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const int row = bi * 4 + r;
+                    const int row = bi * RB + r;
                     const bool match = (unsigned)(x[r][c] >> 32) == epoch;
                     ok = ok && match;
                     if (match && row < rows && kc[c] < Hd) dst[row * HP + kc[c]] = __uint_as_float((unsigned)x[r][c]);
@@ -111,6 +115,12 @@ __device__ __forceinline__ bool sweep_rows(gu64 *src, float *dst, int rows, int 
         }
         __builtin_amdgcn_s_sleep(1);
     }
+}
+
+// One granule store: relaxed, agent scope (sc1, written through), visible to a poll from any XCD.
+__device__ __forceinline__ void publish(gu64 *dst, unsigned epoch, float v)
+{
+    __hip_atomic_store(dst, pack_granule(epoch, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------
@@ -155,20 +165,33 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_kernel(GruParams p)
     const bool gate_lane = unit_ok && ks < kRowTile;
     const size_t G3 = (size_t)3 * Hd;
 
+    // input-projection terms of the first row tile, fetched one step ahead (HBM latency off the critical path)
+    float pre[3] = {0.0f, 0.0f, 0.0f};
+    const bool mine0 = gate_lane && ks < nrows;
+    if (mine0) {
+        const size_t bt = (size_t)(row0 + ks) * p.T;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) pre[g] = p.gi[bt * G3 + g * Hd + u];
+    }
+
     for (int t = 0; t < p.T; ++t) {
         if (t > 0) {
-            const bool ok = sweep_rows(xg + (size_t)((t - 1) & 1) * p.BL * HP, h_s, nrows, Hd, HP, (unsigned)t, p.status);
+            const bool ok = sweep_rows<4>(xg + (size_t)((t - 1) & 1) * p.BL * HP, h_s, nrows, Hd, HP, (unsigned)t, p.status);
             if (!ok && (threadIdx.x & 63) == 0) *fail_s = 1;
         }
         __syncthreads();
         if (*fail_s) break;
         for (int bt0 = 0; bt0 < nrows; bt0 += kRowTile) {
-            // the gate lane of (row, unit): its three input-projection terms, loaded ahead of the products
             const int bl = bt0 + ks;
             const bool mine = gate_lane && bl < nrows;
             const size_t bt = ((size_t)(row0 + bl) * p.T + t);
-            float gir = 0.0f, giz = 0.0f, gin = 0.0f;
-            if (mine) {
+            float gir = pre[0], giz = pre[1], gin = pre[2];
+            if (bt0 == 0) {
+                if (mine && t + 1 < p.T) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) pre[g] = p.gi[(bt + 1) * G3 + g * Hd + u];
+                }
+            } else if (mine) {
                 gir = p.gi[bt * G3 + u];
                 giz = p.gi[bt * G3 + Hd + u];
                 gin = p.gi[bt * G3 + 2 * Hd + u];
@@ -202,10 +225,9 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_kernel(GruParams p)
                 const float ghn = sn + bh[2];
                 const float r = sigmoidf_(gir + (sr + bh[0]));
                 const float z = sigmoidf_(giz + (sz + bh[1]));
-                const float n = tanhf(__fmaf_rn(r, ghn, gin));
+                const float n = tanhf_(__fmaf_rn(r, ghn, gin));
                 const float hnew = __fmaf_rn(hp - n, z, n);
-                __hip_atomic_store(xg + ((size_t)(t & 1) * p.BL + bl) * HP + u, pack_granule((unsigned)t + 1u, hnew),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                publish(xg + ((size_t)(t & 1) * p.BL + bl) * HP + u, (unsigned)t + 1u, hnew);
                 p.y[bt * Hd + u] = hnew;
                 if (p.gates) {
                     p.gates[bt * G3 + u] = r;
@@ -273,33 +295,65 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
         carry[q] = (gate_lane && bl < nrows && p.dhT) ? p.dhT[(size_t)(row0 + bl) * Hd + k] : 0.0f;
     }
 
+    // Everything the gate gradients need besides dh itself is linear in dh: the five factors (and dy) of step t are
+    // prepared one step ahead, so the critical path of a step is one add and five multiplies before the publish.
+    constexpr int Q = kMaxRowsBwd / kRowTile;
+    float dyv[Q], f_r[Q], f_z[Q], f_hn[Q], f_n[Q], f_dir[Q];
+    float raw[Q][6];  // r, z, n, W_hn h + b_hn, h_{t-1}, dy of the NEXT step: loaded a whole step before they are used
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int bl = q * kRowTile + us;
+            if (gate_lane && bl < nrows) {
+                const size_t bt = (size_t)(row0 + bl) * p.T + t;
+                raw[q][0] = p.gates[bt * G3 + k];
+                raw[q][1] = p.gates[bt * G3 + Hd + k];
+                raw[q][2] = p.gates[bt * G3 + 2 * Hd + k];
+                raw[q][3] = p.hn[bt * Hd + k];
+                raw[q][4] = (t > 0) ? p.y[(bt - 1) * Hd + k] : (p.h0 ? p.h0[(size_t)(row0 + bl) * Hd + k] : 0.0f);
+                raw[q][5] = p.dy[bt * Hd + k];
+            }
+        }
+    };
+    auto derive = [&]() {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const float r = raw[q][0], z = raw[q][1], n = raw[q][2], ghn = raw[q][3], hp = raw[q][4];
+            dyv[q] = raw[q][5];
+            f_n[q] = (1.0f - z) * (1.0f - n * n);        // d(n pre-activation) / dh
+            f_r[q] = (f_n[q] * ghn) * (r * (1.0f - r));  // d(r pre-activation) / dh
+            f_z[q] = (hp - n) * (z * (1.0f - z));        // d(z pre-activation) / dh
+            f_hn[q] = f_n[q] * r;                        // d(W_hn h + b_hn) / dh
+            f_dir[q] = z;                                // direct path h_{t-1} -> h_t
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int e = 0; e < 6; ++e) raw[q][e] = 0.0f;
+    fetch(p.T - 1);
+    derive();
+    if (p.T > 1) fetch(p.T - 2);
+
     for (int s = 0; s < p.T; ++s) {
         const int t = p.T - 1 - s;
         const unsigned epoch = (unsigned)s + 1u;
         gu64 *slot = xg + (size_t)(s & 1) * p.BL * 3 * HP;
-        float direct[kMaxRowsBwd / kRowTile];
+        float direct[Q];
         // 1. gate gradients of the owned (row, k) pairs; publish
 #pragma unroll
-        for (int q = 0; q < kMaxRowsBwd / kRowTile; ++q) {
+        for (int q = 0; q < Q; ++q) {
             const int bl = q * kRowTile + us;
             direct[q] = 0.0f;
             if (gate_lane && bl < nrows) {
                 const size_t bt = (size_t)(row0 + bl) * p.T + t;
-                const float dh = p.dy[bt * Hd + k] + carry[q];
-                const float r = p.gates[bt * G3 + k], z = p.gates[bt * G3 + Hd + k], n = p.gates[bt * G3 + 2 * Hd + k];
-                const float ghn = p.hn[bt * Hd + k];
-                const float hp = (t > 0) ? p.y[(bt - 1) * Hd + k] : (p.h0 ? p.h0[(size_t)(row0 + bl) * Hd + k] : 0.0f);
-                const float dz = dh * (hp - n);
-                const float dn = dh * (1.0f - z);
-                const float dn_pre = dn * (1.0f - n * n);
-                const float dr_pre = (dn_pre * ghn) * (r * (1.0f - r));
-                const float dz_pre = dz * (z * (1.0f - z));
-                const float dhn = dn_pre * r;
-                direct[q] = dh * z;
+                const float dh = dyv[q] + carry[q];
+                const float dr_pre = dh * f_r[q], dz_pre = dh * f_z[q], dhn = dh * f_hn[q], dn_pre = dh * f_n[q];
+                direct[q] = dh * f_dir[q];
                 gu64 *gdst = slot + (size_t)bl * 3 * HP + k;
-                __hip_atomic_store(gdst, pack_granule(epoch, dr_pre), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(gdst + HP, pack_granule(epoch, dz_pre), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(gdst + 2 * HP, pack_granule(epoch, dhn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                publish(gdst, epoch, dr_pre);
+                publish(gdst + HP, epoch, dz_pre);
+                publish(gdst + 2 * HP, epoch, dhn);
                 p.d_gi[bt * G3 + k] = dr_pre;
                 p.d_gi[bt * G3 + Hd + k] = dz_pre;
                 p.d_gi[bt * G3 + 2 * Hd + k] = dn_pre;
@@ -310,11 +364,14 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
         }
         // 2. the group's gate gradients -> LDS  (rows of 3 payloads: treated as 3*nrows rows of width Hd)
         {
-            const bool ok = sweep_rows(slot, d_s, 3 * nrows, Hd, HP, epoch, p.status);
+            const bool ok = sweep_rows<12>(slot, d_s, 3 * nrows, Hd, HP, epoch, p.status);
             if (!ok && (threadIdx.x & 63) == 0) *fail_s = 1;
         }
         __syncthreads();
         if (*fail_s) break;
+        // factors of the next step from what was fetched a whole step ago, then the fetch for the step after it
+        derive();
+        if (t > 1) fetch(t - 2);
         // 3. dh_{t-1}[k] = direct + sum over source units
 #pragma unroll
         for (int q = 0; q < kMaxRowsBwd / kRowTile; ++q) {
@@ -360,21 +417,24 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
 
 // ---- host side ----------------------------------------------------------------------------------------------
 struct GruPlan { int KP, HP, NW, NG, NGpad, BL; };
+int g_gru_mode = 0;  // ddsp_gru_set_mode
 
 // Groups / rows per group for a [B, Hd] problem on a device with `cus` compute units; false if it does not fit.
-bool plan_gru(int B, int Hd, int cus, int max_rows, GruPlan *pl)
+// `spread` (test hook): an odd blockIdx modulus NG | 1, which deals every group's workgroups over all XCDs.
+bool plan_gru(int B, int Hd, int cus, int max_rows, bool spread, GruPlan *pl)
 {
     if (Hd > 512) return false;
     pl->KP = Hd <= 64 ? 4 : (Hd <= 128 ? 8 : (Hd <= 256 ? 16 : 32));
     pl->HP = 16 * pl->KP;
     pl->NW = (Hd + kUnits - 1) / kUnits;
     int slots = cus / pl->NW;          // groups that can be co-resident, one workgroup per CU
-    slots -= slots % 8;                // blockIdx modulus is a multiple of 8 (XCD alignment)
-    if (slots < 8) return false;
+    if (spread) slots -= 1;            // room for the padding group of the odd modulus
+    else slots -= slots % 8;           // blockIdx modulus is a multiple of 8 (XCD alignment)
+    if (slots < (spread ? 1 : 8)) return false;
     pl->NG = B < slots ? B : slots;
     pl->BL = (B + pl->NG - 1) / pl->NG;
     pl->NG = (B + pl->BL - 1) / pl->BL;
-    pl->NGpad = (pl->NG + 7) & ~7;
+    pl->NGpad = spread ? (pl->NG | 1) : ((pl->NG + 7) & ~7);
     return pl->BL <= max_rows;
 }
 
@@ -415,7 +475,7 @@ int run_gru(GruParams &p, void *scratch, bool backward, hipStream_t s)
     const int rc = device_cus(&cus);
     if (rc) return rc;
     GruPlan pl;
-    if (!plan_gru(p.B, p.Hd, cus, backward ? kMaxRowsBwd : kMaxRows, &pl)) return DDSP_ERANGE;
+    if (!plan_gru(p.B, p.Hd, cus, backward ? kMaxRowsBwd : kMaxRows, (g_gru_mode & 1) != 0, &pl)) return DDSP_ERANGE;
     p.NG = pl.NG; p.NGpad = pl.NGpad; p.NW = pl.NW; p.BL = pl.BL;
     const int payloads = backward ? 3 : 1;
     // scratch: [status: 256 B][granules]; every polled word is zeroed before EVERY launch (epochs restart at 1)
@@ -448,10 +508,10 @@ extern "C" int ddsp_gru_max_batch(int Hd, int backward)
     int cus = 0;
     if (device_cus(&cus)) return 0;
     GruPlan pl;
-    if (!plan_gru(1, Hd, cus, 1, &pl)) return 0;
+    if (!plan_gru(1, Hd, cus, 1, false, &pl)) return 0;
     int slots = cus / pl.NW;
     slots -= slots % 8;
-    return slots * (backward ? kMaxRowsBwd : kMaxRows);
+    return (slots - 1) * (backward ? kMaxRowsBwd : kMaxRows);   // also valid in the spread test mode
 }
 
 extern "C" int ddsp_gru_forward(const float *gi, const float *w_hh, const float *b_hh, const float *h0, float *y, float *hT,
@@ -478,6 +538,13 @@ extern "C" int ddsp_gru_backward(const float *dy, const float *dhT, const float 
     p.d_gi = d_gi; p.d_gh = d_gh; p.dh0 = dh0;
     p.B = B; p.T = T; p.Hd = Hd;
     return run_gru(p, scratch, true, (hipStream_t)stream);
+}
+
+extern "C" int ddsp_gru_set_mode(int mode)
+{
+    if (mode < 0 || mode > 1) return DDSP_ERANGE;
+    g_gru_mode = mode;
+    return 0;
 }
 
 extern "C" int ddsp_gru_status(const void *scratch, int *status_host)

@@ -1,7 +1,7 @@
 """`GRU`: `torch.nn.GRU` with the recurrence on one persistent HIP launch (include/ddsp_hip.h: ddsp_gru_*).
 
 The reference's control network runs `nn.GRU(2*width, units, layers, batch_first=True)` over the whole clip
-(model/autoencoder/decoder.py:66-70, :91) and over one callback's frames with a carried state in the live path
+(model/autoencoder/decoder.py:60-65, :91) and over one callback's frames with a carried state in the live path
 (:91 via `forward_live` :139-147).  This class IS an `nn.GRU` (same parameters `weight_ih_l0 / weight_hh_l0 /
 bias_ih_l0 / bias_hh_l0`, so the reference's checkpoints load unchanged); for CUDA inputs of a single-layer,
 unidirectional GRU with hidden size <= 512 it computes

@@ -113,7 +113,7 @@ int ddsp_profile_enable(int capacity);
 int ddsp_profile_read(int *kernel_ids, float *ms, int cap);
 
 /*
- * Recurrence of the control network's GRU (model/autoencoder/decoder.py:66-70 builds
+ * Recurrence of the control network's GRU (model/autoencoder/decoder.py:60-65 builds
  * nn.GRU(2*width, units, layers, batch_first=True); :91 runs it).  One persistent launch
  * per direction replaces the ~20 library launches per time step of the stock path; the input projection
  * gi = x W_ih^T + b_ih (and the weight-gradient GEMMs) stay library GEMMs on the caller's side.
@@ -139,6 +139,9 @@ int ddsp_gru_backward(const float *dy, const float *dhT, const float *w_hh, cons
                       const float *gates, const float *hn, float *d_gi, float *d_gh, float *dh0, void *scratch,
                       int B, int T, int Hd, void *stream);
 int ddsp_gru_status(const void *scratch, int *status_host);
+/* Test hook (process-global): 1 deals every group's workgroups over all XCDs (odd blockIdx modulus) instead of keeping
+ * a group on one XCD; 0 restores the default.  Bitwise the same results either way (placement only changes speed). */
+int ddsp_gru_set_mode(int mode);
 
 #ifdef __cplusplus
 }

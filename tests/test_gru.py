@@ -1,5 +1,5 @@
 """GRU recurrence (csrc/ddsp_gru.hip) against torch's own CPU nn.GRU -- what the reference's controller runs
-(model/autoencoder/decoder.py:66-70, :91).  Tolerances: fp32, different summation order: 2e-5 abs on h in [-1, 1],
+(model/autoencoder/decoder.py:60-65, :91).  Tolerances: fp32, different summation order: 2e-5 abs on h in [-1, 1],
 1e-4 of the largest entry on gradients."""
 import numpy as np
 import pytest
@@ -126,3 +126,41 @@ def test_gru_inference_needs_no_saved_tensors_and_rejects_bad_state():
     assert not y.requires_grad
     with pytest.raises(RuntimeError):
         mine(x, torch.zeros(1, 3, 32, device="cuda"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1])
+def test_gru_hand_off_is_placement_independent(mode):
+    """Mode 1 deals every group's workgroups over all XCDs, so every hand-off crosses XCDs: bitwise the same results
+    as the default (one group per XCD), forward and backward, with the GPU busy on a second stream (uneven load)."""
+    from ddsp_pytorch_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(mode)
+    B, T, hd = 6, 60, 512
+    gi = torch.randn(B, T, 3 * hd, device="cuda")
+    w = torch.randn(3 * hd, hd, device="cuda") * 0.05
+    b = torch.randn(3 * hd, device="cuda") * 0.1
+    h0 = torch.randn(B, hd, device="cuda")
+    dy = torch.randn(B, T, hd, device="cuda")
+
+    def run():
+        y, hT, gates, hn = gru_mod.gru_forward(gi, w, b, h0, save=True)
+        assert gru_mod.gru_status(gru_mod.gru_forward.last_scratch) == 0
+        out = gru_mod.gru_backward(dy, None, w, h0, y, gates, hn)
+        assert gru_mod.gru_status(gru_mod.gru_backward.last_scratch) == 0
+        return (y, hT, gates, hn) + tuple(out)
+
+    base = run()
+    side = torch.cuda.Stream()
+    big = torch.randn(4096, 4096, device="cuda")
+    try:
+        assert L.ddsp_gru_set_mode(mode) == 0
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                big = big @ big * 1e-4                          # competing work while the persistent kernels run
+        got = run()
+    finally:
+        L.ddsp_gru_set_mode(0)
+    torch.cuda.synchronize()
+    for a, c in zip(base, got):
+        assert torch.equal(a, c)

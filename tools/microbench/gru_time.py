@@ -27,3 +27,17 @@ for (B, T, n_in, hd) in [(32, 500, 1024, 512), (1, 32, 1024, 512), (1, 16, 1024,
         d = float((ref(x, h0)[0] - mine(x, h0)[0]).abs().max())
     out["max_abs_diff_vs_miopen"] = d
     print(out, flush=True)
+
+# recurrence only (no input-projection GEMM): microseconds per time step
+from ddsp_pytorch_amd import gru as G
+import os
+from ddsp_pytorch_amd import _lib
+_lib.lib().ddsp_gru_set_mode(int(os.environ.get('GRU_MODE', '0')))
+for (B, T, hd) in [(32, 500, 512), (1, 32, 512), (8, 500, 512), (64, 500, 512), (32, 500, 128)]:
+    gi = torch.randn(B, T, 3 * hd, device='cuda'); w = torch.randn(3 * hd, hd, device='cuda') * 0.05
+    b = torch.zeros(3 * hd, device='cuda'); h0 = torch.zeros(B, hd, device='cuda')
+    f = timeit(lambda: G.gru_forward(gi, w, b, h0, save=True))
+    y, hT, gates, hn = G.gru_forward(gi, w, b, h0, save=True)
+    dy = torch.randn_like(y)
+    bw = timeit(lambda: G.gru_backward(dy, None, w, h0, y, gates, hn))
+    print({"mode": os.environ.get("GRU_MODE", "0"), "recurrence": (B, T, hd), "fwd_us_per_step": round(f * 1e3 / T, 2), "bwd_us_per_step": round(bw * 1e3 / T, 2)}, flush=True)
