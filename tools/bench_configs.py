@@ -86,8 +86,47 @@ def run_live(calls=200):
                       "hipgraph_latency_ms_p99": float(np.percentile(glat, 99)), "deadline_ms": 1e3 * 2048 / 44100}), flush=True)
 
 
+def run_live_decoder(calls=200):
+    """The whole callback of rt/synth.py:40-55 = Decoder.forward_live (decoder.py:139-147): controller (MLPs + GRU with a
+    carried state) -> harmonics.live + noise -> reverb.live_forward -> D2H, at config/default.py:8-24 (44.1 kHz, hop 512,
+    180 harmonics, 195 bands, 512-wide MLPs/GRU), 4 frames = 2048 samples per callback.  The same decoder with the stock
+    nn.GRU in place of the HIP recurrence is timed beside it."""
+    import torch.nn as nn
+
+    class Conf:
+        n_harmonics, n_noise_filters, sample_rate, hop_length = 180, 195, 44100, 512
+        decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 512, 3, 512, 1
+
+    torch.manual_seed(0)
+    out = {"config": "rt_live_decoder_default", "samples_per_call": 2048, "deadline_ms": 1e3 * 2048 / 44100}
+    rng = np.random.default_rng(3)
+    z = {"normalized_cents": torch.from_numpy(rng.uniform(0, 1, (1, 4, 1)).astype(np.float32)).cuda(),
+         "loudness": torch.from_numpy(rng.uniform(-1, 1, (1, 4, 1)).astype(np.float32)).cuda(),
+         "f0": torch.from_numpy(rng.uniform(200, 400, (1, 4, 1)).astype(np.float32)).cuda()}
+    for label in ("hip_gru", "stock_gru"):
+        dec = ddsp.Decoder(Conf, noise_rng="device").cuda().eval()
+        if label == "stock_gru":
+            stock = nn.GRU(1024, 512, 1, batch_first=True).cuda()
+            stock.load_state_dict(dec.controller.gru.state_dict())
+            dec.controller.gru = stock
+        hidden = torch.zeros(1, 1, 512, device="cuda")
+        lat = []
+        with torch.no_grad():
+            for i in range(calls + 10):
+                t0 = time.perf_counter()
+                audio, _ = dec.forward_live(z, hidden)
+                if i >= 10:
+                    lat.append(time.perf_counter() - t0)
+        lat = np.array(lat) * 1e3
+        out[label + "_latency_ms_median"] = float(np.median(lat))
+        out[label + "_latency_ms_p99"] = float(np.percentile(lat, 99))
+        assert audio.shape == (2048,) and np.isfinite(audio).all()
+    print(json.dumps(out), flush=True)
+
+
 if __name__ == "__main__":
     run_live()
+    run_live_decoder()
     cfg2 = syn.CFG2
     for shape, seed in ((syn.CFG1, 1001), (cfg2, 1002), (syn.CFG3, 1003), (syn.CFG4_PER_GPU, 1004)):
         run(shape, seed)
