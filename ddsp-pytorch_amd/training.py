@@ -16,6 +16,44 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
+
+
+class _FusedSpectralL1(torch.autograd.Function):
+    """loss = mean|P - Q| + alpha * mean|log2(Q + eps) - log2(P + eps)| over the bins of two complex STFTs given as
+    dense re/im tensors of identical layout; one HIP pass (include/ddsp_hip.h: ddsp_spectral_loss) that also leaves
+    d loss / d pred for the backward."""
+
+    @staticmethod
+    def forward(ctx, pred_ri, true_ri, alpha, eps):
+        L = _lib.lib()
+        need = ctx.needs_input_grad[0]
+        grad = torch.empty_like(pred_ri) if need else None
+        out = torch.empty(3, device=pred_ri.device, dtype=torch.float32)
+        scratch = torch.empty(L.ddsp_spectral_loss_scratch_bytes(), device=pred_ri.device, dtype=torch.uint8)
+        with torch.cuda.device(pred_ri.device):
+            rc = L.ddsp_spectral_loss(pred_ri.data_ptr(), true_ri.data_ptr(), None if grad is None else grad.data_ptr(),
+                                      scratch.data_ptr(), out.data_ptr(), pred_ri.numel() // 2, float(alpha), float(eps),
+                                      torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "ddsp_spectral_loss")
+        if need:
+            ctx.save_for_backward(grad)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
+def _dense_ri(spec: torch.Tensor) -> torch.Tensor:
+    """Complex STFT -> dense float view [..., 2] without a copy when the memory is dense in some axis order
+    (torch.stft returns the transpose of a contiguous [B, frames, bins] tensor); the loss is a sum over bins, so any
+    consistent order will do."""
+    if not spec.is_contiguous() and spec.transpose(-1, -2).is_contiguous():
+        spec = spec.transpose(-1, -2)
+    return torch.view_as_real(spec.contiguous())
+
 
 class SpectralLoss(nn.Module):
     """One scale: L1 of power spectrograms + alpha * L1 of their log2 (loss/mss_loss.py:11-33)."""
@@ -26,12 +64,23 @@ class SpectralLoss(nn.Module):
         self.hop = int(n_fft * (1 - overlap))
         self.register_buffer("window", torch.hann_window(n_fft), persistent=False)
 
-    def power(self, x: torch.Tensor) -> torch.Tensor:
-        spec = torch.stft(x, self.n_fft, hop_length=self.hop, window=self.window.to(x.device), center=True,
+    def stft(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.stft(x, self.n_fft, hop_length=self.hop, window=self.window.to(x.device), center=True,
                           pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+
+    def power(self, x: torch.Tensor) -> torch.Tensor:
+        spec = self.stft(x)
         return spec.real.square() + spec.imag.square()
 
     def forward(self, x_pred, x_true):
+        if x_pred.is_cuda and x_pred.dtype == torch.float32:
+            # GPU: the whole scale after the two library STFTs is one fused HIP pass (forward value + gradient)
+            with torch.no_grad():
+                t_ri = _dense_ri(self.stft(x_true.float()))
+            p_ri = _dense_ri(self.stft(x_pred))
+            if p_ri.shape != t_ri.shape or p_ri.stride() != t_ri.stride():
+                raise ValueError("x_pred and x_true must have the same shape")
+            return _FusedSpectralL1.apply(p_ri, t_ri, self.alpha, self.eps)
         s_true, s_pred = self.power(x_true), self.power(x_pred)
         linear = F.l1_loss(s_pred, s_true)
         log = F.l1_loss(torch.log2(s_true + self.eps), torch.log2(s_pred + self.eps))

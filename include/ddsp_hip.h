@@ -143,6 +143,16 @@ int ddsp_gru_status(const void *scratch, int *status_host);
  * a group on one XCD; 0 restores the default.  Bitwise the same results either way (placement only changes speed). */
 int ddsp_gru_set_mode(int mode);
 
+/*
+ * One scale of the multi-scale spectral loss (loss/mss_loss.py:11-33: L1 of the power spectrograms + alpha * L1 of their
+ * log2) fused into one pass over the two complex STFTs (interleaved re/im, n_bins complex bins each), with the
+ * gradient w.r.t. the predicted STFT produced in the same pass (grad_ri nullable).  out3 (device) = {loss, linear term,
+ * log term}; scratch >= ddsp_spectral_loss_scratch_bytes().  Deterministic summation.  The STFTs stay library FFTs.
+ */
+size_t ddsp_spectral_loss_scratch_bytes(void);
+int ddsp_spectral_loss(const float *pred_ri, const float *true_ri, float *grad_ri, void *scratch, float *out3,
+                       long n_bins, float alpha, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
