@@ -101,21 +101,26 @@ class MSSLoss(nn.Module):
 
 
 def allreduce_gradients(params, group=None) -> int:
-    """Average gradients over the process group with one flat all_reduce. Returns the bucket size in bytes."""
+    """Average gradients over the process group with one flat all_reduce. Returns the bucket size in bytes.
+    The reduced bucket is not copied back: every `p.grad` becomes a view into it (one `cat` launch per step, no
+    per-parameter copies); with a single rank there is nothing to reduce and the gradients are left untouched."""
     import torch.distributed as dist
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    params = [p for p in params if p.grad is not None]
+    if not params:
         return 0
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        flat /= dist.get_world_size(group)
+    nbytes = sum(p.grad.numel() * p.grad.element_size() for p in params)
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if world == 1:
+        return nbytes
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= world
     offset = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[offset:offset + n].view_as(g))
+    for p in params:
+        n = p.grad.numel()
+        p.grad = flat[offset:offset + n].view_as(p)
         offset += n
-    return flat.numel() * flat.element_size()
+    return nbytes
 
 
 def train_step(model: nn.Module, loss_fn: nn.Module, optimizer: torch.optim.Optimizer, batch, group=None):
