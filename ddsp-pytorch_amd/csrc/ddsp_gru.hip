@@ -36,9 +36,9 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 
 constexpr int kUnits = 16;        // hidden units per workgroup (threadIdx.x >> 4)
-constexpr int kRowTile = 4;       // batch rows per register tile
 constexpr int kMaxRows = 64;      // batch rows per group (LDS: 64 x 512 x 4 B = 128 KB forward)
 constexpr int kMaxRowsBwd = 16;   // backward stages 3 payloads per row
+// Batch rows per register tile RT: 4, or 2 when a group has at most two rows (small batches, the live path).
 constexpr long kSpinTicks = 200000000L;  // 2 s of the 100 MHz wall clock
 
 enum { GRU_OK = 0, GRU_TIMEOUT = 1 };
@@ -124,7 +124,7 @@ __device__ __forceinline__ void publish(gu64 *dst, unsigned epoch, float v)
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------
-template <int KP>
+template <int KP, int RT>
 __global__ void __launch_bounds__(256, 1) gru_fwd_kernel(GruParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float h_s[];  // [BLpad][HP] + 1 word (failure flag)
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_kernel(GruParams p)
     const int row0 = group * p.BL;
     const int nrows = min(p.BL, p.B - row0);
     if (nrows <= 0) return;
-    const int BLpad = (p.BL + kRowTile - 1) & ~(kRowTile - 1);
+    const int BLpad = (p.BL + RT - 1) & ~(RT - 1);
     int *fail_s = reinterpret_cast<int *>(h_s + BLpad * HP);
     const int ks = threadIdx.x & 15, ul = threadIdx.x >> 4;
     const int u = member * kUnits + ul;
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_kernel(GruParams p)
     __syncthreads();
 
     gu64 *xg = p.xchg + (size_t)group * 2 * p.BL * HP;  // [2][BL][HP]
-    const bool gate_lane = unit_ok && ks < kRowTile;
+    const bool gate_lane = unit_ok && ks < RT;
     const size_t G3 = (size_t)3 * Hd;
 
     // input-projection terms of the first row tile, fetched one step ahead (HBM latency off the critical path)
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_kernel(GruParams p)
         }
         __syncthreads();
         if (*fail_s) break;
-        for (int bt0 = 0; bt0 < nrows; bt0 += kRowTile) {
+        for (int bt0 = 0; bt0 < nrows; bt0 += RT) {
             const int bl = bt0 + ks;
             const bool mine = gate_lane && bl < nrows;
             const size_t bt = ((size_t)(row0 + bl) * p.T + t);
@@ -196,13 +196,13 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_kernel(GruParams p)
                 giz = p.gi[bt * G3 + Hd + u];
                 gin = p.gi[bt * G3 + 2 * Hd + u];
             }
-            float acc[kRowTile][3];
+            float acc[RT][3];
 #pragma unroll
-            for (int r = 0; r < kRowTile; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0f;
+            for (int r = 0; r < RT; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0f;
 #pragma unroll
             for (int i = 0; i < KP / 4; ++i) {
 #pragma unroll
-                for (int r = 0; r < kRowTile; ++r) {
+                for (int r = 0; r < RT; ++r) {
                     const float4 hv = *reinterpret_cast<const float4 *>(h_s + (bt0 + r) * HP + i * 64 + ks * 4);
 #pragma unroll
                     for (int g = 0; g < 3; ++g) {
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_kernel(GruParams p)
             }
             float sr = 0.0f, sz = 0.0f, sn = 0.0f;
 #pragma unroll
-            for (int r = 0; r < kRowTile; ++r) {
+            for (int r = 0; r < RT; ++r) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) acc[r][g] = ddsp_osc::group_sum(acc[r][g], 4);  // the 16 slices = one DPP row
                 if (ks == r) { sr = acc[r][0]; sz = acc[r][1]; sn = acc[r][2]; }
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_kernel(GruParams p)
 // holds W_hh[g*Hd + u'][k] for its source units u' = 64 i + 4 us + c.  Per step (t = T-1 .. 0) the gate lane of
 // (row, k) turns dh_t into the three pre-activation gradients, publishes them, and after the group-wide exchange
 // dh_{t-1}[k] = dh_t[k] z_t[k] + sum_u' (dr W_hr + dz W_hz + d(hn) W_hn)[u',k]  (+ dy_{t-1}[k] at the next step).
-template <int KP>
+template <int KP, int RT>
 __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float d_s[];  // [BLpad][3][HP] + 1 word
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
     const int row0 = group * p.BL;
     const int nrows = min(p.BL, p.B - row0);
     if (nrows <= 0) return;
-    const int BLpad = (p.BL + kRowTile - 1) & ~(kRowTile - 1);
+    const int BLpad = (p.BL + RT - 1) & ~(RT - 1);
     int *fail_s = reinterpret_cast<int *>(d_s + BLpad * 3 * HP);
     const int us = threadIdx.x & 15, kl = threadIdx.x >> 4;
     const int k = member * kUnits + kl;
@@ -285,25 +285,25 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
     __syncthreads();
 
     gu64 *xg = p.xchg + (size_t)group * 2 * p.BL * 3 * HP;  // [2][BL][3][HP]
-    const bool gate_lane = col_ok && us < kRowTile;
+    const bool gate_lane = col_ok && us < RT;
     const size_t G3 = (size_t)3 * Hd;
-    // running dh for the (row, k) pairs this lane is the gate lane of: rows us, us + 4, ... (register array, <= kMaxRowsBwd/4)
-    float carry[kMaxRowsBwd / kRowTile];
+    // running dh for the (row, k) pairs this lane is the gate lane of: rows us, us + 4, ... (register array, Q of them)
+    constexpr int Q = (RT == 2) ? 1 : kMaxRowsBwd / RT;   // row tiles per group
+    float carry[Q];
 #pragma unroll
-    for (int q = 0; q < kMaxRowsBwd / kRowTile; ++q) {
-        const int bl = q * kRowTile + us;
+    for (int q = 0; q < Q; ++q) {
+        const int bl = q * RT + us;
         carry[q] = (gate_lane && bl < nrows && p.dhT) ? p.dhT[(size_t)(row0 + bl) * Hd + k] : 0.0f;
     }
 
     // Everything the gate gradients need besides dh itself is linear in dh: the five factors (and dy) of step t are
     // prepared one step ahead, so the critical path of a step is one add and five multiplies before the publish.
-    constexpr int Q = kMaxRowsBwd / kRowTile;
     float dyv[Q], f_r[Q], f_z[Q], f_hn[Q], f_n[Q], f_dir[Q];
     float raw[Q][6];  // r, z, n, W_hn h + b_hn, h_{t-1}, dy of the NEXT step: loaded a whole step before they are used
     auto fetch = [&](int t) {
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            const int bl = q * kRowTile + us;
+            const int bl = q * RT + us;
             if (gate_lane && bl < nrows) {
                 const size_t bt = (size_t)(row0 + bl) * p.T + t;
                 raw[q][0] = p.gates[bt * G3 + k];
@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
         // 1. gate gradients of the owned (row, k) pairs; publish
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            const int bl = q * kRowTile + us;
+            const int bl = q * RT + us;
             direct[q] = 0.0f;
             if (gate_lane && bl < nrows) {
                 const size_t bt = (size_t)(row0 + bl) * p.T + t;
@@ -374,18 +374,18 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
         if (t > 1) fetch(t - 2);
         // 3. dh_{t-1}[k] = direct + sum over source units
 #pragma unroll
-        for (int q = 0; q < kMaxRowsBwd / kRowTile; ++q) {
-            const int bt0 = q * kRowTile;
+        for (int q = 0; q < Q; ++q) {
+            const int bt0 = q * RT;
             if (bt0 < nrows) {
-                float acc[kRowTile];
+                float acc[RT];
 #pragma unroll
-                for (int r = 0; r < kRowTile; ++r) acc[r] = 0.0f;
+                for (int r = 0; r < RT; ++r) acc[r] = 0.0f;
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
 #pragma unroll
                     for (int i = 0; i < KP / 4; ++i)
 #pragma unroll
-                        for (int r = 0; r < kRowTile; ++r) {
+                        for (int r = 0; r < RT; ++r) {
                             const float4 dv = *reinterpret_cast<const float4 *>(d_s + ((bt0 + r) * 3 + g) * HP + i * 64 + us * 4);
                             acc[r] = __fmaf_rn(dv.x, w[g][4 * i + 0], acc[r]);
                             acc[r] = __fmaf_rn(dv.y, w[g][4 * i + 1], acc[r]);
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
                         }
                 float mine = 0.0f;
 #pragma unroll
-                for (int r = 0; r < kRowTile; ++r) {
+                for (int r = 0; r < RT; ++r) {
                     acc[r] = ddsp_osc::group_sum(acc[r], 4);
                     if (us == r) mine = acc[r];
                 }
@@ -406,11 +406,11 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
     if (*fail_s) {
         if (threadIdx.x == 0) __hip_atomic_store(p.status, (unsigned)GRU_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int q = 0; q < kMaxRowsBwd / kRowTile; ++q) carry[q] = __builtin_nanf("");
+        for (int q = 0; q < Q; ++q) carry[q] = __builtin_nanf("");
     }
 #pragma unroll
-    for (int q = 0; q < kMaxRowsBwd / kRowTile; ++q) {
-        const int bl = q * kRowTile + us;
+    for (int q = 0; q < Q; ++q) {
+        const int bl = q * RT + us;
         if (gate_lane && bl < nrows) p.dh0[(size_t)(row0 + bl) * Hd + k] = carry[q];
     }
 }
@@ -427,7 +427,8 @@ bool plan_gru(int B, int Hd, int cus, int max_rows, bool spread, GruPlan *pl)
     pl->KP = Hd <= 64 ? 4 : (Hd <= 128 ? 8 : (Hd <= 256 ? 16 : 32));
     pl->HP = 16 * pl->KP;
     pl->NW = (Hd + kUnits - 1) / kUnits;
-    int slots = cus / pl->NW;          // groups that can be co-resident, one workgroup per CU
+    int slots = cus / pl->NW;          // groups that can be co-resident, one workgroup per CU (two per CU measured
+                                       // slower: the waiting workgroup's polls slow its neighbour and the L2)
     if (spread) slots -= 1;            // room for the padding group of the odd modulus
     else slots -= slots % 8;           // blockIdx modulus is a multiple of 8 (XCD alignment)
     if (slots < (spread ? 1 : 8)) return false;
@@ -456,16 +457,16 @@ int device_cus(int *cus)
 
 size_t xchg_bytes(const GruPlan &pl, int payloads) { return (size_t)pl.NG * 2 * pl.BL * payloads * pl.HP * sizeof(unsigned long long); }
 
-template <int KP>
+template <int KP, int RT>
 hipError_t launch_gru(const GruParams &p, bool backward, size_t lds, hipStream_t s)
 {
     static bool attr_f[64] = {}, attr_b[64] = {};
-    const void *fn = backward ? (const void *)gru_bwd_kernel<KP> : (const void *)gru_fwd_kernel<KP>;
+    const void *fn = backward ? (const void *)gru_bwd_kernel<KP, RT> : (const void *)gru_fwd_kernel<KP, RT>;
     const hipError_t e = ddsp_allow_big_lds(fn, backward ? attr_b : attr_f);
     if (e != hipSuccess) return e;
     const dim3 grid((unsigned)(p.NGpad * p.NW)), blk(256);
-    if (backward) hipLaunchKernelGGL(gru_bwd_kernel<KP>, grid, blk, lds, s, p);
-    else hipLaunchKernelGGL(gru_fwd_kernel<KP>, grid, blk, lds, s, p);
+    if (backward) hipLaunchKernelGGL((gru_bwd_kernel<KP, RT>), grid, blk, lds, s, p);
+    else hipLaunchKernelGGL((gru_fwd_kernel<KP, RT>), grid, blk, lds, s, p);
     return hipGetLastError();
 }
 
@@ -483,13 +484,14 @@ int run_gru(GruParams &p, void *scratch, bool backward, hipStream_t s)
     p.xchg = (gu64 *)((char *)scratch + 256);
     hipError_t e = hipMemsetAsync(scratch, 0, 256 + xchg_bytes(pl, payloads), s);
     if (e != hipSuccess) return (int)e;
-    const int BLpad = (pl.BL + kRowTile - 1) & ~(kRowTile - 1);
+    const int RT = pl.BL <= 2 ? 2 : 4;
+    const int BLpad = (pl.BL + RT - 1) & ~(RT - 1);
     const size_t lds = sizeof(float) * ((size_t)BLpad * payloads * pl.HP + 4);
     switch (pl.KP) {
-        case 4: e = launch_gru<4>(p, backward, lds, s); break;
-        case 8: e = launch_gru<8>(p, backward, lds, s); break;
-        case 16: e = launch_gru<16>(p, backward, lds, s); break;
-        default: e = launch_gru<32>(p, backward, lds, s); break;
+#define DDSP_GRU_CASE(KP) case KP: e = (RT == 2) ? launch_gru<KP, 2>(p, backward, lds, s) : launch_gru<KP, 4>(p, backward, lds, s); break;
+        DDSP_GRU_CASE(4) DDSP_GRU_CASE(8) DDSP_GRU_CASE(16)
+        default: e = (RT == 2) ? launch_gru<32, 2>(p, backward, lds, s) : launch_gru<32, 4>(p, backward, lds, s); break;
+#undef DDSP_GRU_CASE
     }
     return (int)e;
 }
