@@ -13,6 +13,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from . import _lib
 from .filtered_noise import FilteredNoise
 from .gru import GRU
 from .harmonic_oscillator import OscillatorBank
@@ -35,8 +36,34 @@ def _run_stack(stack: nn.Module, x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+class _ScaledSigmoid(torch.autograd.Function):
+    """One HIP pass forward, one backward (include/ddsp_hip.h: ddsp_scaled_sigmoid_*)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ddsp_scaled_sigmoid_forward(x.data_ptr(), y.data_ptr(), x.numel(),
+                                                              torch.cuda.current_stream().cuda_stream), "ddsp_scaled_sigmoid_forward")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ddsp_scaled_sigmoid_backward(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), x.numel(),
+                                                               torch.cuda.current_stream().cuda_stream), "ddsp_scaled_sigmoid_backward")
+        return gx
+
+
 def scaled_sigmoid(x: torch.Tensor) -> torch.Tensor:
     """decoder.py:110-116: 2*sigmoid(x)^ln(10) + 1e-7 (the value range of every synth control)."""
+    if x.is_cuda and x.dtype == torch.float32:
+        return _ScaledSigmoid.apply(x)
     return 2.0 * torch.sigmoid(x).pow(2.3026) + 1e-7
 
 

@@ -153,6 +153,13 @@ size_t ddsp_spectral_loss_scratch_bytes(void);
 int ddsp_spectral_loss(const float *pred_ri, const float *true_ri, float *grad_ri, void *scratch, float *out3,
                        long n_bins, float alpha, float eps, void *stream);
 
+/*
+ * The control heads' output non-linearity (model/autoencoder/decoder.py:110-116): y = 2 * sigmoid(x)^2.3026 + 1e-7 over n
+ * fp32 elements, and its backward grad_x = grad_y * dy/dx (x is the forward's input), one elementwise pass each.
+ */
+int ddsp_scaled_sigmoid_forward(const float *x, float *y, long n, void *stream);
+int ddsp_scaled_sigmoid_backward(const float *x, const float *grad_y, float *grad_x, long n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,3 +164,34 @@ def test_gru_hand_off_is_placement_independent(mode):
     torch.cuda.synchronize()
     for a, c in zip(base, got):
         assert torch.equal(a, c)
+
+
+@pytest.mark.gpu
+def test_gru_recurrence_is_graph_capturable():
+    """memset + one kernel, no allocation or synchronisation inside: the launch can sit in a hipGraph (the live path
+    replays one graph per callback); the replay re-zeroes the hand-off granules itself."""
+    torch.manual_seed(4)
+    B, T, hd = 2, 24, 512
+    gi = torch.randn(B, T, 3 * hd, device="cuda")
+    w = torch.randn(3 * hd, hd, device="cuda") * 0.05
+    b = torch.randn(3 * hd, device="cuda") * 0.1
+    h0 = torch.randn(B, hd, device="cuda")
+    ref_y, ref_h, _, _ = gru_mod.gru_forward(gi, w, b, h0, save=False)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        gru_mod.gru_forward(gi, w, b, h0, save=False)          # warm-up on the capture stream
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            y, hT, _, _ = gru_mod.gru_forward(gi, w, b, h0, save=False)
+    for _ in range(3):
+        y.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref_y) and torch.equal(hT, ref_h)
+    gi.mul_(0.5)                                                # new inputs in the captured buffers
+    new_y, _, _, _ = gru_mod.gru_forward(gi, w, b, h0, save=False)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, new_y)
