@@ -52,3 +52,193 @@ extern "C" int ddsp_scaled_sigmoid_backward(const float *x, const float *grad_y,
     hipLaunchKernelGGL(scaled_sigmoid_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, grad_y, grad_x, n);
     return (int)hipGetLastError();
 }
+
+// ---- LayerNorm + LeakyReLU of the MLP blocks (decoder.py:9-39: Linear -> LayerNorm -> LeakyReLU) ------------------
+// One pass forward (y = lrelu(gamma * (x - mean) * rstd + beta); mean and rstd kept per row) and one pass backward
+// (dx, plus per-workgroup partial sums of d gamma / d beta finished by a second small kernel: deterministic) instead of
+// two launches forward and four backward per block.  One wavefront per row, D/64 elements per lane in registers;
+// rows are D = 256 * NV wide (NV = 1..4).  HBM-bound: 8 B per element forward, 16 B backward.
+namespace {
+
+__device__ __forceinline__ float wave_sum64(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int NV>
+__global__ void __launch_bounds__(256) ln_lrelu_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, float *__restrict__ y,
+                                                           float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                                           long rows, float eps, float slope)
+{
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    float4 g[NV], b[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        g[j] = reinterpret_cast<const float4 *>(gamma)[lane + 64 * j];
+        b[j] = reinterpret_cast<const float4 *>(beta)[lane + 64 * j];
+    }
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+        float4 v[NV];
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v[j] = reinterpret_cast<const float4 *>(x + row * D)[lane + 64 * j];
+            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+        const float mean = wave_sum64(s) * (1.0f / D);
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+            q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum64(q) * (1.0f / D) + eps);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            float4 o;
+            o.x = __fmaf_rn(v[j].x * rstd, g[j].x, b[j].x);
+            o.y = __fmaf_rn(v[j].y * rstd, g[j].y, b[j].y);
+            o.z = __fmaf_rn(v[j].z * rstd, g[j].z, b[j].z);
+            o.w = __fmaf_rn(v[j].w * rstd, g[j].w, b[j].w);
+            o.x = o.x > 0.0f ? o.x : o.x * slope;
+            o.y = o.y > 0.0f ? o.y : o.y * slope;
+            o.z = o.z > 0.0f ? o.z : o.z * slope;
+            o.w = o.w > 0.0f ? o.w : o.w * slope;
+            reinterpret_cast<float4 *>(y + row * D)[lane + 64 * j] = o;
+        }
+        if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    }
+}
+
+// partials: [gridDim.x][2][D]  (d gamma | d beta), one slab per workgroup, summed over its four wavefronts through LDS
+template <int NV>
+__global__ void __launch_bounds__(256) ln_lrelu_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ x,
+                                                           const float *__restrict__ y, const float *__restrict__ gamma,
+                                                           const float *__restrict__ mean_in, const float *__restrict__ rstd_in,
+                                                           float *__restrict__ gx, float *__restrict__ partials, long rows, float slope)
+{
+    constexpr int D = 256 * NV;
+    __shared__ float red[4][2][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 g[NV], dg[NV], db[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        g[j] = reinterpret_cast<const float4 *>(gamma)[lane + 64 * j];
+        dg[j] = db[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float4 xh[NV], d[NV];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float4 xv = reinterpret_cast<const float4 *>(x + row * D)[lane + 64 * j];
+            const float4 yv = reinterpret_cast<const float4 *>(y + row * D)[lane + 64 * j];
+            float4 gv = reinterpret_cast<const float4 *>(gy + row * D)[lane + 64 * j];
+            gv.x = yv.x > 0.0f ? gv.x : gv.x * slope;      // the activation keeps the sign of its input (slope > 0)
+            gv.y = yv.y > 0.0f ? gv.y : gv.y * slope;
+            gv.z = yv.z > 0.0f ? gv.z : gv.z * slope;
+            gv.w = yv.w > 0.0f ? gv.w : gv.w * slope;
+            xh[j] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+            dg[j].x += gv.x * xh[j].x; dg[j].y += gv.y * xh[j].y; dg[j].z += gv.z * xh[j].z; dg[j].w += gv.w * xh[j].w;
+            db[j].x += gv.x; db[j].y += gv.y; db[j].z += gv.z; db[j].w += gv.w;
+            d[j] = make_float4(gv.x * g[j].x, gv.y * g[j].y, gv.z * g[j].z, gv.w * g[j].w);
+            s1 += (d[j].x + d[j].y) + (d[j].z + d[j].w);
+            s2 += (d[j].x * xh[j].x + d[j].y * xh[j].y) + (d[j].z * xh[j].z + d[j].w * xh[j].w);
+        }
+        const float m1 = wave_sum64(s1) * (1.0f / D), m2 = wave_sum64(s2) * (1.0f / D);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            float4 o;
+            o.x = rstd * (d[j].x - m1 - xh[j].x * m2);
+            o.y = rstd * (d[j].y - m1 - xh[j].y * m2);
+            o.z = rstd * (d[j].z - m1 - xh[j].z * m2);
+            o.w = rstd * (d[j].w - m1 - xh[j].w * m2);
+            reinterpret_cast<float4 *>(gx + row * D)[lane + 64 * j] = o;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        reinterpret_cast<float4 *>(red[wave][0])[lane + 64 * j] = dg[j];
+        reinterpret_cast<float4 *>(red[wave][1])[lane + 64 * j] = db[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        const int which = i / D, c = i - which * D;
+        partials[((size_t)blockIdx.x * 2 + which) * D + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+}
+
+// columns of the [blocks][2*D] partial slabs -> d gamma | d beta; 64 columns x 16 row groups per workgroup, fixed order
+__global__ void __launch_bounds__(1024) ln_lrelu_finish_kernel(const float *__restrict__ partials, int blocks, int D,
+                                                               float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;   // c over 2 * D columns
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;   // four loads in flight per thread
+    int b = grp;
+    for (; b + 48 < blocks; b += 64) {
+        s0 += partials[(size_t)b * 2 * D + c];
+        s1 += partials[(size_t)(b + 16) * 2 * D + c];
+        s2 += partials[(size_t)(b + 32) * 2 * D + c];
+        s3 += partials[(size_t)(b + 48) * 2 * D + c];
+    }
+    for (; b < blocks; b += 16) s0 += partials[(size_t)b * 2 * D + c];
+    red[grp][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x & 63];
+        if (c < D) dgamma[c] = t; else dbeta[c - D] = t;
+    }
+}
+
+constexpr int kLnBlocks = 1024;  // four workgroups per CU: enough rows in flight to cover the HBM latency
+
+}  // namespace
+
+extern "C" size_t ddsp_ln_lrelu_scratch_bytes(int D) { return D > 0 ? sizeof(float) * 2 * (size_t)D * kLnBlocks : 0; }
+
+extern "C" int ddsp_ln_lrelu_forward(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd,
+                                     long rows, int D, float eps, float slope, void *stream)
+{
+    if (rows == 0) return 0;
+    if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 0) return DDSP_EINVAL;
+    if (D <= 0 || D % 256 != 0 || D > 1024) return DDSP_ERANGE;
+    const long want = (rows + 3) / 4;
+    const dim3 grid((unsigned)(want < 4096 ? want : 4096)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (D / 256) {
+        case 1: hipLaunchKernelGGL(ln_lrelu_fwd_kernel<1>, grid, blk, 0, s, x, gamma, beta, y, mean, rstd, rows, eps, slope); break;
+        case 2: hipLaunchKernelGGL(ln_lrelu_fwd_kernel<2>, grid, blk, 0, s, x, gamma, beta, y, mean, rstd, rows, eps, slope); break;
+        case 3: hipLaunchKernelGGL(ln_lrelu_fwd_kernel<3>, grid, blk, 0, s, x, gamma, beta, y, mean, rstd, rows, eps, slope); break;
+        default: hipLaunchKernelGGL(ln_lrelu_fwd_kernel<4>, grid, blk, 0, s, x, gamma, beta, y, mean, rstd, rows, eps, slope); break;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int ddsp_ln_lrelu_backward(const float *grad_y, const float *x, const float *y, const float *gamma, const float *mean,
+                                      const float *rstd, float *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
+                                      long rows, int D, float slope, void *stream)
+{
+    if (!grad_y || !x || !y || !gamma || !mean || !rstd || !grad_x || !grad_gamma || !grad_beta || !scratch || rows <= 0) return DDSP_EINVAL;
+    if (D <= 0 || D % 256 != 0 || D > 1024) return DDSP_ERANGE;
+    const long want = (rows + 3) / 4;
+    const int blocks = (int)(want < kLnBlocks ? want : kLnBlocks);
+    const dim3 grid((unsigned)blocks), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    float *part = (float *)scratch;
+    switch (D / 256) {
+        case 1: hipLaunchKernelGGL(ln_lrelu_bwd_kernel<1>, grid, blk, 0, s, grad_y, x, y, gamma, mean, rstd, grad_x, part, rows, slope); break;
+        case 2: hipLaunchKernelGGL(ln_lrelu_bwd_kernel<2>, grid, blk, 0, s, grad_y, x, y, gamma, mean, rstd, grad_x, part, rows, slope); break;
+        case 3: hipLaunchKernelGGL(ln_lrelu_bwd_kernel<3>, grid, blk, 0, s, grad_y, x, y, gamma, mean, rstd, grad_x, part, rows, slope); break;
+        default: hipLaunchKernelGGL(ln_lrelu_bwd_kernel<4>, grid, blk, 0, s, grad_y, x, y, gamma, mean, rstd, grad_x, part, rows, slope); break;
+    }
+    hipLaunchKernelGGL(ln_lrelu_finish_kernel, dim3((unsigned)(2 * D / 64)), dim3(1024), 0, s, part, blocks, D, grad_gamma, grad_beta);
+    return (int)hipGetLastError();
+}

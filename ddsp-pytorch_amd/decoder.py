@@ -30,9 +30,53 @@ def _dense_stack(n_in: int, width: int, depth: int) -> nn.Module:
     return stack
 
 
+class _LayerNormLeakyReLU(torch.autograd.Function):
+    """LayerNorm -> LeakyReLU of one MLP block as one HIP pass each way (include/ddsp_hip.h: ddsp_ln_lrelu_*)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, slope):
+        x = x.contiguous()
+        D = x.shape[-1]
+        rows = x.numel() // D
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ddsp_ln_lrelu_forward(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                        rstd.data_ptr(), rows, D, float(eps), float(slope),
+                                                        torch.cuda.current_stream().cuda_stream), "ddsp_ln_lrelu_forward")
+        ctx.save_for_backward(x, y, g, mean, rstd)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, g, mean, rstd = ctx.saved_tensors
+        D = x.shape[-1]
+        rows = x.numel() // D
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        dg, db = torch.empty_like(g), torch.empty_like(g)
+        L = _lib.lib()
+        scratch = torch.empty(L.ddsp_ln_lrelu_scratch_bytes(D), device=x.device, dtype=torch.uint8)
+        with torch.cuda.device(x.device):
+            _lib.check(L.ddsp_ln_lrelu_backward(gy.data_ptr(), x.data_ptr(), y.data_ptr(), g.data_ptr(), mean.data_ptr(),
+                                                rstd.data_ptr(), gx.data_ptr(), dg.data_ptr(), db.data_ptr(), scratch.data_ptr(),
+                                                rows, D, ctx.slope, torch.cuda.current_stream().cuda_stream), "ddsp_ln_lrelu_backward")
+        return gx, dg, db, None, None
+
+
 def _run_stack(stack: nn.Module, x: torch.Tensor) -> torch.Tensor:
     for i in range(stack.depth):
-        x = getattr(stack, f"mlp_layer{i + 1}")(x)
+        linear, norm, act = getattr(stack, f"mlp_layer{i + 1}")
+        x = linear(x)
+        D = x.shape[-1]
+        if (x.is_cuda and x.dtype == torch.float32 and D % 256 == 0 and D <= 1024 and norm.elementwise_affine
+                and norm.bias is not None and act.negative_slope > 0):
+            x = _LayerNormLeakyReLU.apply(x, norm.weight, norm.bias, norm.eps, act.negative_slope)
+        else:
+            x = act(norm(x))
     return x
 
 

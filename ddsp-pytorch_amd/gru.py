@@ -28,8 +28,9 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def gru_forward(gi, w_hh, b_hh, h0, save: bool):
-    """Raw launcher of ddsp_gru_forward. gi [B,T,3Hd] -> (y [B,T,Hd], hT [B,Hd], gates | None, hn | None)."""
+def gru_forward(gi, w_hh, b_hh, h0, save: bool, scratch_out: list | None = None):
+    """Raw launcher of ddsp_gru_forward. gi [B,T,3Hd] -> (y [B,T,Hd], hT [B,Hd], gates | None, hn | None).
+    `scratch_out` (tests): receives the scratch buffer of every launch, for `gru_status`."""
     B, T, G3 = gi.shape
     Hd = G3 // 3
     L = _lib.lib()
@@ -51,11 +52,12 @@ def gru_forward(gi, w_hh, b_hh, h0, save: bool):
                                     y[lo:hi].data_ptr(), hT[lo:hi].data_ptr(), _ptr(gates[lo:hi]) if save else None,
                                     _ptr(hn[lo:hi]) if save else None, scratch.data_ptr(), hi - lo, T, Hd, stream)
             _lib.check(rc, "ddsp_gru_forward")
-            gru_forward.last_scratch = scratch
+            if scratch_out is not None:
+                scratch_out.append(scratch)
     return y, hT, gates, hn
 
 
-def gru_backward(dy, dhT, w_hh, h0, y, gates, hn):
+def gru_backward(dy, dhT, w_hh, h0, y, gates, hn, scratch_out: list | None = None):
     """Raw launcher of ddsp_gru_backward -> (d_gi [B,T,3Hd], d_gh [B,T,3Hd], dh0 [B,Hd])."""
     B, T, Hd = y.shape
     L = _lib.lib()
@@ -73,7 +75,8 @@ def gru_backward(dy, dhT, w_hh, h0, y, gates, hn):
                                      hn[lo:hi].data_ptr(), d_gi[lo:hi].data_ptr(), d_gh[lo:hi].data_ptr(), dh0[lo:hi].data_ptr(),
                                      scratch.data_ptr(), hi - lo, T, Hd, stream)
             _lib.check(rc, "ddsp_gru_backward")
-            gru_backward.last_scratch = scratch
+            if scratch_out is not None:
+                scratch_out.append(scratch)
     return d_gi, d_gh, dh0
 
 

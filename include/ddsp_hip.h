@@ -160,6 +160,19 @@ int ddsp_spectral_loss(const float *pred_ri, const float *true_ri, float *grad_r
 int ddsp_scaled_sigmoid_forward(const float *x, float *y, long n, void *stream);
 int ddsp_scaled_sigmoid_backward(const float *x, const float *grad_y, float *grad_x, long n, void *stream);
 
+/*
+ * LayerNorm followed by LeakyReLU over rows of D = 256, 512, 768 or 1024 fp32 elements (the MLP blocks of
+ * model/autoencoder/decoder.py:9-39 after their Linear): y = lrelu(gamma * (x - mean) * rstd + beta); the forward keeps
+ * mean / rstd per row for the backward, which returns grad_x and (deterministically summed) grad_gamma / grad_beta.
+ * scratch >= ddsp_ln_lrelu_scratch_bytes(D).
+ */
+size_t ddsp_ln_lrelu_scratch_bytes(int D);
+int ddsp_ln_lrelu_forward(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd,
+                          long rows, int D, float eps, float slope, void *stream);
+int ddsp_ln_lrelu_backward(const float *grad_y, const float *x, const float *y, const float *gamma, const float *mean,
+                           const float *rstd, float *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
+                           long rows, int D, float slope, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

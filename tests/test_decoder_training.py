@@ -218,3 +218,34 @@ def test_fused_scaled_sigmoid_matches_torch_formulation():
     (yg * w.cuda()).sum().backward()
     assert float((yg.detach().cpu() - yc.detach()).abs().max()) <= 2e-6
     assert float((xg.grad.cpu() - xc.grad).abs().max()) <= 2e-6 * max(1.0, float(xc.grad.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [256, 512, 1024])
+def test_fused_layernorm_leakyrelu_matches_torch_layers(D):
+    from ddsp_pytorch_amd.decoder import _dense_stack, _run_stack
+    torch.manual_seed(D)
+    stack = _dense_stack(7, D, 2)
+    with torch.no_grad():
+        for i in (1, 2):
+            ln = getattr(stack, f"mlp_layer{i}")[1]
+            ln.weight.uniform_(0.5, 1.5)
+            ln.bias.uniform_(-0.3, 0.3)
+    x0 = torch.randn(5, 37, 7)
+    w = torch.randn(5, 37, D)
+
+    def run(mod, dev):
+        mod = mod.to(dev)
+        for p in mod.parameters():
+            p.grad = None
+        x = x0.clone().to(dev).requires_grad_(True)
+        y = _run_stack(mod, x)                                  # CPU: stock layers; GPU: Linear + the fused pass
+        (y * w.to(dev)).sum().backward()
+        return y.detach().cpu(), x.grad.cpu(), {k: p.grad.detach().cpu().clone() for k, p in mod.named_parameters()}
+
+    y_ref, gx_ref, gp_ref = run(stack, "cpu")
+    y, gx, gp = run(stack, "cuda")
+    assert float((y - y_ref).abs().max()) <= 1e-5
+    assert float((gx - gx_ref).abs().max()) <= 1e-4 * float(gx_ref.abs().max())
+    for k in gp_ref:
+        assert float((gp[k] - gp_ref[k]).abs().max()) <= 1e-4 * (float(gp_ref[k].abs().max()) + 1e-9), k
