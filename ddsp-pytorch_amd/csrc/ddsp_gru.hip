@@ -38,7 +38,7 @@ typedef __attribute__((address_space(1))) unsigned int gu32;
 constexpr int kUnits = 16;        // hidden units per workgroup (threadIdx.x >> 4)
 constexpr int kMaxRows = 64;      // batch rows per group (LDS: 64 x 512 x 4 B = 128 KB forward)
 constexpr int kMaxRowsBwd = 16;   // backward stages 3 payloads per row
-// Batch rows per register tile RT: 4, or 2 when a group has at most two rows (small batches, the live path).
+// Batch rows per register tile RT (2 or 4) and row sets NRS (1 or 2 x 256 threads): see launch_gru.
 constexpr long kSpinTicks = 200000000L;  // 2 s of the 100 MHz wall clock
 
 enum { GRU_OK = 0, GRU_TIMEOUT = 1 };
@@ -73,16 +73,33 @@ __device__ __forceinline__ unsigned long long pack_granule(unsigned epoch, float
 }
 
 // Polls `rows` granule rows of width Hd (row stride HP granules) until every tag equals `epoch`; values go to LDS.
-// A thread owns columns tid and tid + 256 of every row; rows are polled RB at a time (2 RB independent loads in
+// A thread owns columns tid and tid + NT (NT = workgroup size) of every row; rows are polled RB at a time (2 RB independent loads in
 // flight per lane), and a batch whose tags all matched is not polled again.  Returns false (wave-uniform) on
 // timeout / abort.
-template <int RB>
-__device__ __forceinline__ bool sweep_rows(gu64 *src, float *dst, int rows, int Hd, int HP, unsigned epoch, gu32 *status)
+template <int RB, bool FIRST_LIGHT>
+__device__ __forceinline__ bool sweep_rows(gu64 *src, float *dst, int rows, int Hd, int HP, unsigned epoch, gu32 *status, int NT)
 {
     const long t0 = wall_clock64();
-    const int kc[2] = {(int)threadIdx.x, (int)threadIdx.x + 256};
+    const int kc[2] = {(int)threadIdx.x, (int)threadIdx.x + NT};
     const int nb = (rows + RB - 1) / RB;                  // <= 16 batches
     unsigned todo = (1u << nb) - 1u;
+    // First light: a full pass moves rows x Hd granules per workgroup through the L2 and takes about as long as the
+    // hand-off itself, so a pass that starts a little too early costs a whole extra pass (measured: +2 us per
+    // backward step).  Each lane first watches ONE granule -- its own column of the last row, the last one its
+    // publisher stores -- with cheap passes, and only then reads (and checks the tag of) everything.  Used where a pass is
+    // heavy (backward, three payloads per row); the forward's 8-load passes are cheaper than the extra round trip.
+    if (FIRST_LIGHT && kc[0] < Hd) {
+        gu64 *sentinel = src + (size_t)(rows - 1) * HP + kc[0];
+        for (unsigned pass = 0;; ++pass) {
+            const unsigned long long x = __hip_atomic_load(sentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((unsigned)(x >> 32) == epoch)) break;
+            if ((pass & 63) == 63) {
+                if (wall_clock64() - t0 > kSpinTicks) return false;
+                if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
     for (unsigned pass = 0;; ++pass) {
         for (int bi = 0; bi < nb; ++bi) {
             if (!((todo >> bi) & 1u)) continue;           // wave-uniform
@@ -124,8 +141,8 @@ __device__ __forceinline__ void publish(gu64 *dst, unsigned epoch, float v)
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------
-template <int KP, int RT>
-__global__ void __launch_bounds__(256, 1) gru_fwd_kernel(GruParams p)
+template <int KP, int RT, int NRS>
+__global__ void __launch_bounds__(256 * NRS, 1) gru_fwd_kernel(GruParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float h_s[];  // [BLpad][HP] + 1 word (failure flag)
     constexpr int HP = 16 * KP;
@@ -136,7 +153,8 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_kernel(GruParams p)
     if (nrows <= 0) return;
     const int BLpad = (p.BL + RT - 1) & ~(RT - 1);
     int *fail_s = reinterpret_cast<int *>(h_s + BLpad * HP);
-    const int ks = threadIdx.x & 15, ul = threadIdx.x >> 4;
+    const int rs = threadIdx.x >> 8, lt = threadIdx.x & 255;   // row set, thread within the set
+    const int ks = lt & 15, ul = lt >> 4;
     const int u = member * kUnits + ul;
     const int Hd = p.Hd;
     const bool unit_ok = u < Hd;
@@ -154,7 +172,7 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_kernel(GruParams p)
 #pragma unroll
     for (int g = 0; g < 3; ++g) bh[g] = (unit_ok && p.b_hh) ? p.b_hh[g * Hd + u] : 0.0f;
 
-    for (int i = threadIdx.x; i < BLpad * HP; i += 256) {
+    for (int i = threadIdx.x; i < BLpad * HP; i += 256 * NRS) {
         const int bl = i / HP, k = i - bl * HP;
         h_s[i] = (bl < nrows && k < Hd && p.h0) ? p.h0[(size_t)(row0 + bl) * Hd + k] : 0.0f;
     }
@@ -167,26 +185,26 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_kernel(GruParams p)
 
     // input-projection terms of the first row tile, fetched one step ahead (HBM latency off the critical path)
     float pre[3] = {0.0f, 0.0f, 0.0f};
-    const bool mine0 = gate_lane && ks < nrows;
+    const bool mine0 = gate_lane && rs * RT + ks < nrows;
     if (mine0) {
-        const size_t bt = (size_t)(row0 + ks) * p.T;
+        const size_t bt = (size_t)(row0 + rs * RT + ks) * p.T;
 #pragma unroll
         for (int g = 0; g < 3; ++g) pre[g] = p.gi[bt * G3 + g * Hd + u];
     }
 
     for (int t = 0; t < p.T; ++t) {
         if (t > 0) {
-            const bool ok = sweep_rows<4>(xg + (size_t)((t - 1) & 1) * p.BL * HP, h_s, nrows, Hd, HP, (unsigned)t, p.status);
+            const bool ok = sweep_rows<4, false>(xg + (size_t)((t - 1) & 1) * p.BL * HP, h_s, nrows, Hd, HP, (unsigned)t, p.status, 256 * NRS);
             if (!ok && (threadIdx.x & 63) == 0) *fail_s = 1;
         }
         __syncthreads();
         if (*fail_s) break;
-        for (int bt0 = 0; bt0 < nrows; bt0 += RT) {
+        for (int bt0 = rs * RT; bt0 < nrows; bt0 += RT * NRS) {
             const int bl = bt0 + ks;
             const bool mine = gate_lane && bl < nrows;
             const size_t bt = ((size_t)(row0 + bl) * p.T + t);
             float gir = pre[0], giz = pre[1], gin = pre[2];
-            if (bt0 == 0) {
+            if (bt0 == rs * RT) {
                 if (mine && t + 1 < p.T) {
 #pragma unroll
                     for (int g = 0; g < 3; ++g) pre[g] = p.gi[(bt + 1) * G3 + g * Hd + u];
@@ -243,7 +261,7 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_kernel(GruParams p)
     if (*fail_s) {
         if (threadIdx.x == 0) __hip_atomic_store(p.status, (unsigned)GRU_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int bl = ks; bl < nrows; bl += 16)
-            if (unit_ok) {
+            if (unit_ok && rs == 0) {
                 p.hT[(size_t)(row0 + bl) * Hd + u] = __builtin_nanf("");
                 p.y[((size_t)(row0 + bl) * p.T + (p.T - 1)) * Hd + u] = __builtin_nanf("");
             }
@@ -255,8 +273,8 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_kernel(GruParams p)
 // holds W_hh[g*Hd + u'][k] for its source units u' = 64 i + 4 us + c.  Per step (t = T-1 .. 0) the gate lane of
 // (row, k) turns dh_t into the three pre-activation gradients, publishes them, and after the group-wide exchange
 // dh_{t-1}[k] = dh_t[k] z_t[k] + sum_u' (dr W_hr + dz W_hz + d(hn) W_hn)[u',k]  (+ dy_{t-1}[k] at the next step).
-template <int KP, int RT>
-__global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
+template <int KP, int RT, int NRS>
+__global__ void __launch_bounds__(256 * NRS, 1) gru_bwd_kernel(GruParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float d_s[];  // [BLpad][3][HP] + 1 word
     constexpr int HP = 16 * KP;
@@ -267,7 +285,8 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
     if (nrows <= 0) return;
     const int BLpad = (p.BL + RT - 1) & ~(RT - 1);
     int *fail_s = reinterpret_cast<int *>(d_s + BLpad * 3 * HP);
-    const int us = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int rs = threadIdx.x >> 8, lt = threadIdx.x & 255;   // row set, thread within the set
+    const int us = lt & 15, kl = lt >> 4;
     const int k = member * kUnits + kl;
     const int Hd = p.Hd;
     const bool col_ok = k < Hd;
@@ -280,7 +299,7 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
             const int uu = (e >> 2) * 64 + us * 4 + (e & 3);
             w[g][e] = (col_ok && uu < Hd) ? p.w_hh[((size_t)g * Hd + uu) * Hd + k] : 0.0f;
         }
-    for (int i = threadIdx.x; i < BLpad * 3 * HP; i += 256) d_s[i] = 0.0f;
+    for (int i = threadIdx.x; i < BLpad * 3 * HP; i += 256 * NRS) d_s[i] = 0.0f;
     if (threadIdx.x == 0) *fail_s = 0;
     __syncthreads();
 
@@ -288,11 +307,11 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
     const bool gate_lane = col_ok && us < RT;
     const size_t G3 = (size_t)3 * Hd;
     // running dh for the (row, k) pairs this lane is the gate lane of: rows us, us + 4, ... (register array, Q of them)
-    constexpr int Q = (RT == 2) ? 1 : kMaxRowsBwd / RT;   // row tiles per group
+    constexpr int Q = (RT == 2 && NRS == 1) ? 1 : kMaxRowsBwd / (RT * NRS);   // row tiles per row set: tile q of set rs = q * NRS + rs
     float carry[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        const int bl = q * RT + us;
+        const int bl = (q * NRS + rs) * RT + us;
         carry[q] = (gate_lane && bl < nrows && p.dhT) ? p.dhT[(size_t)(row0 + bl) * Hd + k] : 0.0f;
     }
 
@@ -303,7 +322,7 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
     auto fetch = [&](int t) {
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            const int bl = q * RT + us;
+            const int bl = (q * NRS + rs) * RT + us;
             if (gate_lane && bl < nrows) {
                 const size_t bt = (size_t)(row0 + bl) * p.T + t;
                 raw[q][0] = p.gates[bt * G3 + k];
@@ -343,7 +362,7 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
         // 1. gate gradients of the owned (row, k) pairs; publish
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            const int bl = q * RT + us;
+            const int bl = (q * NRS + rs) * RT + us;
             direct[q] = 0.0f;
             if (gate_lane && bl < nrows) {
                 const size_t bt = (size_t)(row0 + bl) * p.T + t;
@@ -364,7 +383,7 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
         }
         // 2. the group's gate gradients -> LDS  (rows of 3 payloads: treated as 3*nrows rows of width Hd)
         {
-            const bool ok = sweep_rows<12>(slot, d_s, 3 * nrows, Hd, HP, epoch, p.status);
+            const bool ok = sweep_rows<12, NRS == 1>(slot, d_s, 3 * nrows, Hd, HP, epoch, p.status, 256 * NRS);
             if (!ok && (threadIdx.x & 63) == 0) *fail_s = 1;
         }
         __syncthreads();
@@ -375,7 +394,7 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
         // 3. dh_{t-1}[k] = direct + sum over source units
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            const int bt0 = q * RT;
+            const int bt0 = (q * NRS + rs) * RT;
             if (bt0 < nrows) {
                 float acc[RT];
 #pragma unroll
@@ -410,7 +429,7 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_kernel(GruParams p)
     }
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        const int bl = q * RT + us;
+        const int bl = (q * NRS + rs) * RT + us;
         if (gate_lane && bl < nrows) p.dh0[(size_t)(row0 + bl) * Hd + k] = carry[q];
     }
 }
@@ -457,17 +476,36 @@ int device_cus(int *cus)
 
 size_t xchg_bytes(const GruPlan &pl, int payloads) { return (size_t)pl.NG * 2 * pl.BL * payloads * pl.HP * sizeof(unsigned long long); }
 
-template <int KP, int RT>
-hipError_t launch_gru(const GruParams &p, bool backward, size_t lds, hipStream_t s)
+template <int KP, int RT, int NRS>
+hipError_t launch_fwd(const GruParams &p, size_t lds, hipStream_t s)
 {
-    static bool attr_f[64] = {}, attr_b[64] = {};
-    const void *fn = backward ? (const void *)gru_bwd_kernel<KP, RT> : (const void *)gru_fwd_kernel<KP, RT>;
-    const hipError_t e = ddsp_allow_big_lds(fn, backward ? attr_b : attr_f);
+    static bool attr[64] = {};
+    const hipError_t e = ddsp_allow_big_lds((const void *)gru_fwd_kernel<KP, RT, NRS>, attr);
     if (e != hipSuccess) return e;
-    const dim3 grid((unsigned)(p.NGpad * p.NW)), blk(256);
-    if (backward) hipLaunchKernelGGL((gru_bwd_kernel<KP, RT>), grid, blk, lds, s, p);
-    else hipLaunchKernelGGL((gru_fwd_kernel<KP, RT>), grid, blk, lds, s, p);
+    hipLaunchKernelGGL((gru_fwd_kernel<KP, RT, NRS>), dim3((unsigned)(p.NGpad * p.NW)), dim3(256 * NRS), lds, s, p);
     return hipGetLastError();
+}
+
+template <int KP, int RT, int NRS>
+hipError_t launch_bwd(const GruParams &p, size_t lds, hipStream_t s)
+{
+    static bool attr[64] = {};
+    const hipError_t e = ddsp_allow_big_lds((const void *)gru_bwd_kernel<KP, RT, NRS>, attr);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((gru_bwd_kernel<KP, RT, NRS>), dim3((unsigned)(p.NGpad * p.NW)), dim3(256 * NRS), lds, s, p);
+    return hipGetLastError();
+}
+
+// Shapes of a workgroup, chosen by same-box A/B (tools/ab_gru.sh): rows per register tile RT and row sets NRS (256 threads
+// each, holding the same weights, taking every other tile).  One wavefront per SIMD issues a VALU instruction every 4+
+// cycles, so the forward's 384 FMAs + reductions of a 4-row tile (1.45 us of a 2.4 us step by in-kernel timers) run faster
+// as two 2-row tiles on two wavefronts per SIMD; the backward prefers one set with a 4-row tile up to 4 rows per group.
+template <int KP>
+hipError_t launch_gru(const GruParams &p, bool backward, int RT, int NRS, size_t lds, hipStream_t s)
+{
+    if (!backward) return NRS == 1 ? launch_fwd<KP, 2, 1>(p, lds, s) : launch_fwd<KP, 2, 2>(p, lds, s);
+    if (RT == 4) return launch_bwd<KP, 4, 1>(p, lds, s);
+    return NRS == 1 ? launch_bwd<KP, 2, 1>(p, lds, s) : launch_bwd<KP, 2, 2>(p, lds, s);
 }
 
 int run_gru(GruParams &p, void *scratch, bool backward, hipStream_t s)
@@ -484,14 +522,15 @@ int run_gru(GruParams &p, void *scratch, bool backward, hipStream_t s)
     p.xchg = (gu64 *)((char *)scratch + 256);
     hipError_t e = hipMemsetAsync(scratch, 0, 256 + xchg_bytes(pl, payloads), s);
     if (e != hipSuccess) return (int)e;
-    const int RT = pl.BL <= 2 ? 2 : 4;
+    const int RT = (backward && pl.BL > 2 && pl.BL <= 4) ? 4 : 2;
+    const int NRS = (pl.BL <= 2 || RT == 4) ? 1 : 2;
     const int BLpad = (pl.BL + RT - 1) & ~(RT - 1);
     const size_t lds = sizeof(float) * ((size_t)BLpad * payloads * pl.HP + 4);
     switch (pl.KP) {
-#define DDSP_GRU_CASE(KP) case KP: e = (RT == 2) ? launch_gru<KP, 2>(p, backward, lds, s) : launch_gru<KP, 4>(p, backward, lds, s); break;
-        DDSP_GRU_CASE(4) DDSP_GRU_CASE(8) DDSP_GRU_CASE(16)
-        default: e = (RT == 2) ? launch_gru<32, 2>(p, backward, lds, s) : launch_gru<32, 4>(p, backward, lds, s); break;
-#undef DDSP_GRU_CASE
+        case 4: e = launch_gru<4>(p, backward, RT, NRS, lds, s); break;
+        case 8: e = launch_gru<8>(p, backward, RT, NRS, lds, s); break;
+        case 16: e = launch_gru<16>(p, backward, RT, NRS, lds, s); break;
+        default: e = launch_gru<32>(p, backward, RT, NRS, lds, s); break;
     }
     return (int)e;
 }

@@ -8,9 +8,9 @@ def timeit(fn, n=10, warm=3):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
-for mode in (0, 1, 0):
+for mode in (0, 1, 0, 1):
     L.ddsp_gru_set_mode(mode)
-    for (B, T, hd) in [(32, 500, 512), (1, 500, 512)]:
+    for (B, T, hd) in [(16, 500, 512), (4, 500, 512), (1, 500, 512)]:
         gi = torch.randn(B, T, 3 * hd, device='cuda'); w = torch.randn(3 * hd, hd, device='cuda') * 0.05
         b = torch.zeros(3 * hd, device='cuda'); h0 = torch.zeros(B, hd, device='cuda')
         f = timeit(lambda: G.gru_forward(gi, w, b, h0, save=True))
