@@ -49,6 +49,8 @@ def lib():
     L.ddsp_osc_forward.argtypes = [vp] * 8 + [i32] * 5 + [vp]
     L.ddsp_noise_forward.restype = i32
     L.ddsp_noise_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, u64, u64, i32, vp]
+    L.ddsp_noise_forward_counter.restype = i32
+    L.ddsp_noise_forward_counter.argtypes = [vp, vp, i32, i32, i32, i32, u64, vp, i32, vp]
     L.ddsp_osc_set_tiling.restype = i32
     L.ddsp_osc_set_tiling.argtypes = [i32]
     L.ddsp_osc_backward_scratch_bytes.restype = ctypes.c_size_t
@@ -95,7 +97,7 @@ def lib():
     return L
 
 
-EXPORTS = ("ddsp_hip_abi_version", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_noise_forward",
+EXPORTS = ("ddsp_hip_abi_version", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_noise_forward", "ddsp_noise_forward_counter",
            "ddsp_osc_backward_scratch_bytes", "ddsp_osc_backward", "ddsp_noise_backward",
            "ddsp_osc_set_tiling", "ddsp_noise_set_generic", "ddsp_profile_enable", "ddsp_profile_read",
            "ddsp_gru_scratch_bytes", "ddsp_gru_max_batch", "ddsp_gru_forward", "ddsp_gru_backward", "ddsp_gru_status", "ddsp_gru_set_mode",

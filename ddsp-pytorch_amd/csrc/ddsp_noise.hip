@@ -28,6 +28,7 @@ struct NoiseParams {
     float *y;
     int B, T, F, R, S;
     uint64_t seed, offset;
+    const uint64_t *offset_dev;  // nullable: the draw starts at offset + *offset_dev (a device counter: hipGraph replays)
     int accumulate;
     int lpf_log; // batched kernel: log2(lanes per frame) -> 64 >> lpf_log frames per workgroup
 };
@@ -70,7 +71,7 @@ __global__ void __launch_bounds__(256) noise_frame_kernel(NoiseParams p)
     } else {
         const int quads = (R + 3) >> 2;
         for (int q = tid; q < quads; q += 256) {
-            const uint64_t ctr = p.offset + (uint64_t)frame * (uint64_t)quads + (uint64_t)q;
+            const uint64_t ctr = p.offset + (p.offset_dev ? *p.offset_dev : 0ull) + (uint64_t)frame * (uint64_t)quads + (uint64_t)q;
             uint32_t r[4];
             philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r);
 #pragma unroll
@@ -230,7 +231,7 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
         const int quads = R >> 2;                        // R % 8 == 0 here
         for (int e = tid; e < FB * quads; e += kNT) {
             const int f = e / quads, q = e - f * quads;
-            const uint64_t ctr = p.offset + (uint64_t)(frame0 + f) * (uint64_t)quads + (uint64_t)q;
+            const uint64_t ctr = p.offset + (p.offset_dev ? *p.offset_dev : 0ull) + (uint64_t)(frame0 + f) * (uint64_t)quads + (uint64_t)q;
             uint32_t r[4];
             philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r);
             float4 v;
@@ -540,15 +541,34 @@ int pick_lpf_log(int F, int R)
 
 }  // namespace
 
+namespace {
+int noise_forward_impl(const float *Hmag, const float *uniform, float *y, int B, int T, int F, int hop, uint64_t seed,
+                       uint64_t offset, const uint64_t *offset_dev, int accumulate, void *stream);
+}
+
 extern "C" int ddsp_noise_forward(const float *Hmag, const float *uniform, float *y, int B, int T, int F, int hop,
                                   uint64_t seed, uint64_t offset, int accumulate, void *stream)
+{
+    return noise_forward_impl(Hmag, uniform, y, B, T, F, hop, seed, offset, nullptr, accumulate, stream);
+}
+
+extern "C" int ddsp_noise_forward_counter(const float *Hmag, float *y, int B, int T, int F, int hop, uint64_t seed,
+                                          const uint64_t *counter_dev, int accumulate, void *stream)
+{
+    if (!counter_dev) return DDSP_EINVAL;
+    return noise_forward_impl(Hmag, nullptr, y, B, T, F, hop, seed, 0, counter_dev, accumulate, stream);
+}
+
+namespace {
+int noise_forward_impl(const float *Hmag, const float *uniform, float *y, int B, int T, int F, int hop, uint64_t seed,
+                       uint64_t offset, const uint64_t *offset_dev, int accumulate, void *stream)
 {
     if (B == 0) return 0;
     if (!Hmag || !y || B < 0 || T <= 0 || F < 2 || hop <= 0) return DDSP_EINVAL;
     NoiseParams p;
     p.Hm = Hmag; p.u = uniform; p.y = y;
     p.B = B; p.T = T; p.F = F; p.R = hop; p.S = 2 * (F - 1);
-    p.seed = seed; p.offset = offset; p.accumulate = accumulate; p.lpf_log = 0;
+    p.seed = seed; p.offset = offset; p.offset_dev = offset_dev; p.accumulate = accumulate; p.lpf_log = 0;
     if ((long)B * T >= (1L << 31)) return DDSP_ERANGE;
     hipStream_t s = (hipStream_t)stream;
     const int lpf_log = pick_lpf_log(F, hop);
@@ -572,6 +592,7 @@ extern "C" int ddsp_noise_forward(const float *Hmag, const float *uniform, float
     ddsp_prof::end(slot, s);
     return (int)hipGetLastError();
 }
+}  // namespace
 
 extern "C" int ddsp_noise_set_generic(int on)
 {

@@ -13,8 +13,10 @@ import torch.nn as nn
 from . import _lib
 
 
-def noise_forward(Hmag, hop: int, uniform=None, seed: int = 0, offset: int = 0, out=None, accumulate=False):
-    """Raw launcher over the C ABI (include/ddsp_hip.h: ddsp_noise_forward)."""
+def noise_forward(Hmag, hop: int, uniform=None, seed: int = 0, offset: int = 0, out=None, accumulate=False, counter=None):
+    """Raw launcher over the C ABI (include/ddsp_hip.h: ddsp_noise_forward).
+    `counter`: a 1-element int64 CUDA tensor holding the Philox offset of the in-kernel draw (read on the device at
+    launch time, so a captured launch draws from wherever the counter stands at each replay); excludes `uniform`."""
     if Hmag.dim() != 3:
         raise ValueError("expected H [B,T,F]")
     if not Hmag.is_cuda:
@@ -34,8 +36,14 @@ def noise_forward(Hmag, hop: int, uniform=None, seed: int = 0, offset: int = 0, 
         uniform = uniform.detach().to(device=Hmag.device, dtype=torch.float32).contiguous()
     with torch.cuda.device(Hmag.device):
         stream = torch.cuda.current_stream().cuda_stream
-        rc = _lib.lib().ddsp_noise_forward(Hmag.data_ptr(), None if uniform is None else uniform.data_ptr(),
-                                           out.data_ptr(), B, T, F, hop, seed, offset, 1 if accumulate else 0, stream)
+        if counter is not None:
+            if uniform is not None or counter.dtype != torch.int64 or counter.numel() != 1 or not counter.is_cuda:
+                raise ValueError("counter must be a 1-element int64 CUDA tensor and excludes an injected draw")
+            rc = _lib.lib().ddsp_noise_forward_counter(Hmag.data_ptr(), out.data_ptr(), B, T, F, hop, seed, counter.data_ptr(),
+                                                       1 if accumulate else 0, stream)
+        else:
+            rc = _lib.lib().ddsp_noise_forward(Hmag.data_ptr(), None if uniform is None else uniform.data_ptr(),
+                                               out.data_ptr(), B, T, F, hop, seed, offset, 1 if accumulate else 0, stream)
     _lib.check(rc, "ddsp_noise_forward")
     return out
 

@@ -29,7 +29,8 @@ class GraphedSynth:
         self.H = torch.ones((batch, frames, n_noise_filters), device=dev)
         self.state = torch.zeros(H, device=dev)           # last_phases (fp32, as after the reference's first live call)
         self.seed = noise_seed
-        self._step = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._step = torch.zeros(1, dtype=torch.int64, device=dev)     # Philox offset of the next call's draw
+        self._draws_per_call = batch * frames * ((conf.hop_length + 3) // 4)
         self.out = None
         self._graph = None
         self._capture()
@@ -41,14 +42,17 @@ class GraphedSynth:
             self.state.copy_(new_state)
         else:
             y, _, _ = osc_forward(self.f0, self.c, self.a, self.hop, self.sample_rate)
-        # the draw is fixed by (seed, offset) at capture time: replays reuse the same noise realisation unless the caller
-        # re-seeds and re-captures; pass noise through `H` scaling if a different realisation per call matters
-        return noise_forward(self.H, self.hop, seed=self.seed, out=y, accumulate=True)
+        # the Philox offset of the draw lives on the device and advances inside the graph: every replay is fresh noise,
+        # the same sequence as un-captured calls with offset = call index x draws per call
+        y = noise_forward(self.H, self.hop, seed=self.seed, out=y, accumulate=True, counter=self._step)
+        self._step.add_(self._draws_per_call)
+        return y
 
     def _capture(self):
         if not self.f0.is_cuda:
             raise _lib.DdspHipError("GraphedSynth needs a GPU")
         saved = self.state.clone()
+        self._step.zero_()
         side = torch.cuda.Stream(device=self.f0.device)
         side.wait_stream(torch.cuda.current_stream(self.f0.device))
         with torch.cuda.stream(side):
@@ -60,6 +64,7 @@ class GraphedSynth:
         with torch.cuda.graph(self._graph):
             self.out = self._pass()
         self.state.copy_(saved)
+        self._step.zero_()
 
     def run(self):
         """Replay the captured pass on the current controls; returns the static output tensor [B, T*hop]."""
@@ -70,3 +75,76 @@ class GraphedSynth:
         for name in ("f0", "c", "a", "H"):
             getattr(self, name).copy_(ctrl[name], non_blocking=True)
         return self.run()
+
+
+class GraphedLiveDecoder:
+    """The whole real-time callback (rt/synth.py:40-55 -> `Decoder.forward_live`, decoder.py:139-147) as ONE hipGraph:
+    controller (MLPs, GRU recurrence, heads) -> harmonics.live + noise -> reverb.live_forward.  Per callback the host does
+    three small H2D copies into the static inputs, one replay and one D2H of the audio.  Every piece of state stays on
+    the device and is advanced by nodes of the graph: the oscillator phases (`state`), the reverb's one-second history
+    (`decoder.reverb.buffer`), the Philox offset of the noise draw, and the GRU state (`hidden_out`; the reference hands
+    the callback's INPUT state back, SURVEY App. C.7 -- `carry_hidden=True` feeds the new one forward instead).
+    """
+
+    def __init__(self, decoder, frames: int, noise_seed: int = 0, carry_hidden: bool = False):
+        self.dec = decoder.eval()
+        dev = next(decoder.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.DdspHipError("GraphedLiveDecoder needs the decoder on a GPU")
+        osc = decoder.harmonics
+        self.hop, self.sample_rate = osc.hop_size, osc.sample_rate
+        self.frames, self.seed, self.carry_hidden = frames, noise_seed, carry_hidden
+        self.z = {k: torch.zeros(1, frames, 1, device=dev) for k in ("normalized_cents", "loudness", "f0")}
+        self.z["f0"].fill_(100.0)
+        units = decoder.controller.gru.hidden_size
+        self.hidden = torch.zeros(1, 1, units, device=dev)
+        self.hidden_out = torch.zeros(1, 1, units, device=dev)
+        self.state = osc.last_phases.data.detach().to(device=dev, dtype=torch.float32).clone()
+        self._step = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._draws_per_call = frames * ((self.hop + 3) // 4)
+        self.out = None
+        self._capture()
+
+    def _pass(self):
+        with torch.no_grad():
+            ctrl, _ = self.dec.controller(self.z, self.hidden)
+            y, new_state, _ = osc_forward(ctrl["f0"], ctrl["c"], ctrl["a"], self.hop, self.sample_rate, live_in=self.state,
+                                          want_live_out=True)
+            self.state.copy_(new_state)
+            noise_forward(ctrl["H"], self.hop, seed=self.seed, out=y, accumulate=True, counter=self._step)
+            self._step.add_(self._draws_per_call)
+            audio = self.dec.reverb.live_forward(y)
+            self.hidden_out.copy_(ctrl["hidden"])
+            if self.carry_hidden:
+                self.hidden.copy_(ctrl["hidden"])
+            return audio.contiguous()
+
+    def _capture(self):
+        dev = self.state.device
+        keep = (self.state.clone(), self.dec.reverb.buffer.data.clone(), self.hidden.clone())
+
+        def restore():
+            self.state.copy_(keep[0])
+            self.dec.reverb.buffer.data.copy_(keep[1])
+            self.hidden.copy_(keep[2])
+            self._step.zero_()
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._pass()                      # warm-up: FFT plans, library handles, allocator pools
+        torch.cuda.current_stream(dev).wait_stream(side)
+        restore()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self.out = self._pass()
+        restore()
+
+    def run(self, z):
+        """z: dict of `normalized_cents`, `loudness`, `f0`, each [1, frames, 1] (numpy or tensor) -> audio [frames*hop] (numpy)."""
+        for k, buf in self.z.items():
+            v = z[k]
+            buf.copy_(v if torch.is_tensor(v) else torch.from_numpy(v), non_blocking=True)
+        self._graph.replay()
+        return self.out.cpu().squeeze(0).numpy()

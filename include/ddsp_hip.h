@@ -70,6 +70,10 @@ int ddsp_osc_forward(const float *f0, const float *c, const float *a, float *y, 
 int ddsp_noise_forward(const float *Hmag, const float *uniform, float *y,
                        int B, int T, int F, int hop, uint64_t seed, uint64_t offset,
                        int accumulate, void *stream);
+/* Same with the in-kernel draw starting at *counter_dev (a device uint64 the caller advances between calls, e.g. by a
+ * node of the same hipGraph: a replayed graph then draws fresh noise every time).  counter_dev is only read. */
+int ddsp_noise_forward_counter(const float *Hmag, float *y, int B, int T, int F, int hop, uint64_t seed,
+                               const uint64_t *counter_dev, int accumulate, void *stream);
 
 /*
  * Backward of ddsp_osc_forward w.r.t. c and a (autograd of harmonic_oscillator.py:24-62; f0 carries no gradient,

@@ -249,3 +249,32 @@ def test_fused_layernorm_leakyrelu_matches_torch_layers(D):
     assert float((gx - gx_ref).abs().max()) <= 1e-4 * float(gx_ref.abs().max())
     for k in gp_ref:
         assert float((gp[k] - gp_ref[k]).abs().max()) <= 1e-4 * (float(gp_ref[k].abs().max()) + 1e-9), k
+
+
+@pytest.mark.gpu
+def test_graphed_live_decoder_equals_eager_callbacks():
+    """The whole rt callback as one hipGraph (GraphedLiveDecoder) against `Decoder.forward_live` called eagerly: same audio
+    for three consecutive callbacks -- oscillator phases, reverb history and the noise stream are carried inside the graph."""
+    class Conf:
+        n_harmonics, n_noise_filters, sample_rate, hop_length = 60, 65, 16000, 128
+        decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 256, 2, 128, 1
+
+    torch.manual_seed(11)
+    eager = ddsp.Decoder(Conf, noise_rng="device", seed=5).cuda().eval()
+    with torch.no_grad():
+        eager.reverb.wet.fill_(0.3)
+    graphed_model = ddsp.Decoder(Conf, noise_rng="device", seed=5).cuda().eval()
+    graphed_model.load_state_dict(eager.state_dict())
+    live = ddsp.GraphedLiveDecoder(graphed_model, frames=4, noise_seed=5)
+    rng = np.random.default_rng(8)
+    hidden = torch.zeros(1, 1, 128, device="cuda")
+    for call in range(3):
+        z = {"normalized_cents": rng.uniform(0, 1, (1, 4, 1)).astype(np.float32),
+             "loudness": rng.uniform(-1, 1, (1, 4, 1)).astype(np.float32),
+             "f0": rng.uniform(150, 400, (1, 4, 1)).astype(np.float32)}
+        with torch.no_grad():
+            ref, _ = eager.forward_live({k: torch.from_numpy(v).cuda() for k, v in z.items()}, hidden)
+        got = live.run(z)
+        assert got.shape == ref.shape == (512,)
+        assert np.max(np.abs(got - ref)) <= 1e-6, call
+    assert torch.equal(live.state, eager.harmonics.last_phases.data)

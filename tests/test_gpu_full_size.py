@@ -125,13 +125,18 @@ def test_graphed_synth_offline_and_live():
     eager, _, _ = ddsp.osc_forward(x["f0"], x["c"], x["a"], 128, 16000)
     ddsp.noise_forward(x["H"], 128, seed=3, out=eager, accumulate=True)
     assert torch.equal(y, eager)
-    assert torch.equal(gs(x), eager)                         # replay is deterministic
+    # the second replay draws fresh noise: the Philox offset lives on the device and advances inside the graph,
+    # exactly like un-captured calls with offset = call index x draws per call
+    eager2, _, _ = ddsp.osc_forward(x["f0"], x["c"], x["a"], 128, 16000)
+    ddsp.noise_forward(x["H"], 128, seed=3, offset=1 * 40 * 32, out=eager2, accumulate=True)
+    y2 = gs(x)
+    assert torch.equal(y2, eager2) and not torch.equal(y2, eager)
     # live: the graph carries the oscillator state exactly like OscillatorBank.live
     gl = ddsp.GraphedSynth(Conf, 1, 4, 65, live=True, noise_seed=3)
     osc = ddsp.OscillatorBank(Conf).cuda()
     for call in range(3):
         ctl2, x2 = controls(syn.SynthShape("l", 1, 16000, 128, 4, 60, 65), 30 + call, "musical")
         ref = osc.live(x2)
-        ddsp.noise_forward(x2["H"], 128, seed=3, out=ref, accumulate=True)
+        ddsp.noise_forward(x2["H"], 128, seed=3, offset=call * 4 * 32, out=ref, accumulate=True)
         assert torch.equal(gl(x2), ref)
         assert torch.equal(gl.state, osc.last_phases.data)
