@@ -47,6 +47,17 @@ def test_argument_validation_without_gpu():
     assert L.ddsp_osc_forward(None, None, None, None, None, None, None, None, 0, 1, 1, 1, 16000, None) == 0  # empty batch
     assert L.ddsp_noise_forward(None, None, None, 1, 1, 65, 128, 0, 0, 0, None) == -1
     assert L.ddsp_osc_set_tiling(7) == -2 and L.ddsp_osc_set_tiling(0) == 0
+    # the callers' entry points validate before touching the device as well
+    assert L.ddsp_noise_forward_counter(None, None, 1, 1, 65, 128, 0, None, 0, None) == -1
+    assert L.ddsp_gru_forward(None, None, None, None, None, None, None, None, None, 1, 1, 16, None) == -1
+    assert L.ddsp_gru_forward(None, None, None, None, None, None, None, None, None, 0, 1, 16, None) == 0   # empty batch
+    assert L.ddsp_gru_backward(None, None, None, None, None, None, None, None, None, None, None, 1, 1, 16, None) == -1
+    assert L.ddsp_gru_scratch_bytes(4, 1024) == 0 and L.ddsp_gru_scratch_bytes(4, 512) > 0   # hidden sizes up to 512
+    assert L.ddsp_gru_set_mode(7) == -2 and L.ddsp_gru_set_mode(0) == 0
+    assert L.ddsp_spectral_loss(None, None, None, None, None, 10, 1.0, 1e-7, None) == -1
+    assert L.ddsp_scaled_sigmoid_forward(None, None, 10, None) == -1 and L.ddsp_scaled_sigmoid_forward(None, None, 0, None) == 0
+    assert L.ddsp_ln_lrelu_forward(None, None, None, None, None, None, 4, 512, 1e-5, 0.01, None) == -1
+    assert L.ddsp_ln_lrelu_scratch_bytes(512) > 0
 
 
 def test_module_boundary_matches_reference_contract():
