@@ -278,3 +278,30 @@ def test_graphed_live_decoder_equals_eager_callbacks():
         assert got.shape == ref.shape == (512,)
         assert np.max(np.abs(got - ref)) <= 1e-6, call
     assert torch.equal(live.state, eager.harmonics.last_phases.data)
+
+
+@pytest.mark.gpu
+def test_decoder_live_callbacks_match_reference_fixture():
+    """The real-time path end to end: three consecutive `forward_live` callbacks of the reference's
+    Decoder on the CPU (fixture G14: fixed weights, carried input state, per-call seeded noise) against ours on the GPU --
+    oscillator phases and reverb history persist between the calls exactly like the reference's."""
+    g = load_golden("g14_decoder_live_callbacks")
+
+    class C:
+        n_harmonics, n_noise_filters, sample_rate, hop_length = 16, 9, 4000, 64
+        decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 16, 2, 12, 1
+
+    dec = ddsp.Decoder(C)                                        # noise_rng='host': the reference's RNG semantics
+    dec.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w__")}, strict=True)
+    dec = dec.cuda().eval()
+    hidden = torch.from_numpy(g["hidden"]).cuda()
+    for call in range(3):
+        z = {k: torch.from_numpy(g[f"{k}_{call}"]).cuda() for k in ("normalized_cents", "loudness", "f0")}
+        with torch.no_grad():
+            torch.manual_seed(140 + call)
+            audio, h_ret = dec.forward_live(z, hidden)
+        assert h_ret is hidden
+        ref = g[f"audio_{call}"]
+        assert audio.shape == ref.shape == (8 * 64,)
+        assert np.max(np.abs(audio - ref)) <= 2e-5 * max(1.0, float(np.max(np.abs(ref)))), call
+    assert np.array_equal(dec.harmonics.last_phases.detach().cpu().numpy(), g["last_phases"])   # phases: bit-exact state

@@ -325,9 +325,41 @@ def g13():
     save("g13_decoder_end_to_end", **batch, **arrays, y=y.numpy(), y_short=y_short.numpy())
 
 
+def g14():
+    # the real-time callback: the reference Decoder.forward_live (decoder.py:139-147) called three times on the CPU with
+    # fixed weights and a carried GRU input state -- oscillator phases (harmonic_oscillator.py:70-72) and reverb history
+    # (reverb.py:41-49) persist between the calls; each call's noise draw is seeded right before it.
+    from model.autoencoder.decoder import Decoder as RefDecoder
+
+    class C:
+        n_harmonics, n_noise_filters, sample_rate, hop_length = 16, 9, 4000, 64
+        decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 16, 2, 12, 1
+
+    torch.manual_seed(1414)
+    dec = RefDecoder(C)
+    with torch.no_grad():
+        dec.reverb.wet.fill_(0.5)
+        dec.reverb.decay.fill_(3.0)
+    arrays = {f"w__{k}": v.numpy().copy() for k, v in dec.state_dict().items()}   # before the calls mutate the state
+    rng = np.random.default_rng(114)
+    hidden = torch.from_numpy(rng.standard_normal((1, 1, 12)).astype(np.float32))
+    out = {}
+    for call in range(3):
+        z = {"normalized_cents": rng.uniform(0, 1, (1, 8, 1)).astype(np.float32),
+             "loudness": rng.uniform(-1, 1, (1, 8, 1)).astype(np.float32),
+             "f0": rng.uniform(60, 300, (1, 8, 1)).astype(np.float32)}
+        torch.manual_seed(140 + call)
+        audio, h_ret = dec.forward_live({k: t(v) for k, v in z.items()}, hidden)
+        assert h_ret is hidden                                       # App. C.7: the INPUT state comes back
+        out.update({f"{k}_{call}": v for k, v in z.items()})
+        out[f"audio_{call}"] = np.asarray(audio, dtype=np.float32)
+    save("g14_decoder_live_callbacks", **arrays, **out, hidden=hidden.numpy(),
+         last_phases=dec.harmonics.last_phases.detach().numpy().astype(np.float32))
+
+
 if __name__ == "__main__":
     print("torch", torch.__version__, "threads", torch.get_num_threads())
     only = sys.argv[1:]
-    for fn in (g1, g2_g3_g4, g5, g6, g7, g8, g9, g10, g11, g12, g13):
+    for fn in (g1, g2_g3_g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14):
         if not only or fn.__name__ in only:
             fn()
