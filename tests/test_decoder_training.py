@@ -305,3 +305,31 @@ def test_decoder_live_callbacks_match_reference_fixture():
         assert audio.shape == ref.shape == (8 * 64,)
         assert np.max(np.abs(audio - ref)) <= 2e-5 * max(1.0, float(np.max(np.abs(ref)))), call
     assert np.array_equal(dec.harmonics.last_phases.detach().cpu().numpy(), g["last_phases"])   # phases: bit-exact state
+
+
+@pytest.mark.gpu
+def test_decoder_gradients_match_reference_autograd_fixture():
+    """Gradients end to end (fixture G15): loss = sum(audio * weight) through the reference's Decoder on the CPU, the
+    reference's own autograd for all 37 trainable tensors (controller MLPs, GRU, heads, reverb) -- against our Decoder on
+    the GPU: HIP backward of the oscillator bank and the noise, GRU recurrence backward, fused head non-linearity."""
+    g = load_golden("g15_decoder_gradients")
+
+    class C:
+        n_harmonics, n_noise_filters, sample_rate, hop_length = 16, 9, 4000, 64
+        decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 16, 2, 12, 1
+
+    dec = ddsp.Decoder(C)
+    dec.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w__")}, strict=True)
+    dec = dec.cuda()
+    batch = {k: torch.from_numpy(g[k]).cuda() for k in ("normalized_cents", "loudness", "f0")}
+    torch.manual_seed(150)
+    y = dec(batch)
+    (y * torch.from_numpy(g["weight"]).cuda()).sum().backward()
+    assert np.max(np.abs(y.detach().cpu().numpy() - g["y"])) <= 2e-5 * max(1.0, float(np.max(np.abs(g["y"]))))
+    names = [k[3:] for k in g if k.startswith("g__")]
+    got = dict(dec.named_parameters())
+    assert len(names) == 37 and {n for n, p in got.items() if p.grad is not None} == set(names)
+    for n in names:
+        ref = g["g__" + n]
+        err = float(np.max(np.abs(got[n].grad.cpu().numpy() - ref)))
+        assert err <= 2e-4 * max(1.0, float(np.max(np.abs(ref)))), (n, err)

@@ -357,9 +357,38 @@ def g14():
          last_phases=dec.harmonics.last_phases.detach().numpy().astype(np.float32))
 
 
+def g15():
+    # gradients end to end: the reference Decoder.forward (decoder.py:127-135) on the CPU, loss = sum(audio * weight), and the
+    # reference's own autograd for EVERY trainable parameter (controller MLPs / GRU / heads, reverb) -- what train/train.py:32-37
+    # differentiates, without the (torchaudio-based) spectral loss.
+    from model.autoencoder.decoder import Decoder as RefDecoder
+
+    class C:
+        n_harmonics, n_noise_filters, sample_rate, hop_length = 16, 9, 4000, 64
+        decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 16, 2, 12, 1
+
+    torch.manual_seed(1515)
+    dec = RefDecoder(C)
+    with torch.no_grad():
+        dec.reverb.wet.fill_(0.5)
+        dec.reverb.decay.fill_(3.0)
+    arrays = {f"w__{k}": v.numpy().copy() for k, v in dec.state_dict().items()}
+    rng = np.random.default_rng(115)
+    batch = {"normalized_cents": rng.uniform(0, 1, (2, 70, 1)).astype(np.float32),
+             "loudness": rng.uniform(-1, 1, (2, 70, 1)).astype(np.float32),
+             "f0": rng.uniform(60, 300, (2, 70, 1)).astype(np.float32)}
+    weight = rng.standard_normal((2, 70 * 64)).astype(np.float32)
+    with torch.enable_grad():
+        torch.manual_seed(150)
+        y = dec({k: t(v) for k, v in batch.items()})
+        (y * t(weight)).sum().backward()
+    grads = {f"g__{k}": p.grad.numpy().copy() for k, p in dec.named_parameters() if p.requires_grad and p.grad is not None}
+    save("g15_decoder_gradients", **batch, **arrays, **grads, weight=weight, y=y.detach().numpy())
+
+
 if __name__ == "__main__":
     print("torch", torch.__version__, "threads", torch.get_num_threads())
     only = sys.argv[1:]
-    for fn in (g1, g2_g3_g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14):
+    for fn in (g1, g2_g3_g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15):
         if not only or fn.__name__ in only:
             fn()
