@@ -113,17 +113,23 @@ __device__ __forceinline__ bool sweep_rows(gu64 *src, float *dst, int rows, int 
                     if (row < rows && kc[c] < Hd)
                         x[r][c] = __hip_atomic_load(src + (size_t)row * HP + kc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-            bool ok = true;
+            bool ok = true;   // lanes / rows outside the problem carry the expected tag already
 #pragma unroll
             for (int r = 0; r < RB; ++r)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
+                for (int c = 0; c < 2; ++c) ok = ok && (unsigned)(x[r][c] >> 32) == epoch;
+            if (__all(ok)) {   // the whole batch arrived: store it without per-granule predication
+                todo &= ~(1u << bi);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
                     const int row = bi * RB + r;
-                    const bool match = (unsigned)(x[r][c] >> 32) == epoch;
-                    ok = ok && match;
-                    if (match && row < rows && kc[c] < Hd) dst[row * HP + kc[c]] = __uint_as_float((unsigned)x[r][c]);
+                    if (row < rows) {
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                            if (kc[c] < Hd) dst[row * HP + kc[c]] = __uint_as_float((unsigned)x[r][c]);
+                    }
                 }
-            if (__all(ok)) todo &= ~(1u << bi);
+            }
         }
         if (todo == 0u) return true;
         if ((pass & 63) == 63) {
