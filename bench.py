@@ -18,14 +18,41 @@ the reference's CPU path (oracle/torch_restatement.py) on this box's host cores 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks under torch.distributed.run as a CHILD
+    process (this parent has not imported torch nor touched the GPU, and never execs), let rank 0's JSON line through
+    on the inherited stdout and return the launcher's exit code (non-zero if any rank failed)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    # decide before torch / the HIP library are imported: the parent of a multi-rank run stays GPU-free
+    _pre = argparse.ArgumentParser(add_help=False)
+    _pre.add_argument("--gpus", type=int, default=1)
+    _n = _pre.parse_known_args()[0].gpus
+    if _n > 1:
+        sys.exit(self_launch(_n))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 import ddsp_pytorch_amd as ddsp  # noqa: E402
 from ddsp_pytorch_amd import synthetic as syn  # noqa: E402

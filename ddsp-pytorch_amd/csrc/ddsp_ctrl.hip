@@ -226,8 +226,14 @@ extern "C" int ddsp_ln_lrelu_backward(const float *grad_y, const float *x, const
                                       const float *rstd, float *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
                                       long rows, int D, float slope, void *stream)
 {
-    if (!grad_y || !x || !y || !gamma || !mean || !rstd || !grad_x || !grad_gamma || !grad_beta || !scratch || rows <= 0) return DDSP_EINVAL;
     if (D <= 0 || D % 256 != 0 || D > 1024) return DDSP_ERANGE;
+    if (rows == 0) {   // an empty shard (batch < world size): no rows contribute, the parameter gradients are zero
+        if (!grad_gamma || !grad_beta) return DDSP_EINVAL;
+        hipError_t e = hipMemsetAsync(grad_gamma, 0, sizeof(float) * (size_t)D, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipMemsetAsync(grad_beta, 0, sizeof(float) * (size_t)D, (hipStream_t)stream);
+        return (int)e;
+    }
+    if (!grad_y || !x || !y || !gamma || !mean || !rstd || !grad_x || !grad_gamma || !grad_beta || !scratch || rows < 0) return DDSP_EINVAL;
     const long want = (rows + 3) / 4;
     const int blocks = (int)(want < kLnBlocks ? want : kLnBlocks);
     const dim3 grid((unsigned)blocks), blk(256);

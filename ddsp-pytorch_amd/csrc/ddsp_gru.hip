@@ -26,6 +26,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "ddsp_hip.h"
 #include "ddsp_internal.h"
 #include "ddsp_osc_common.h"
@@ -40,6 +42,7 @@ constexpr int kMaxRows = 64;      // batch rows per group (LDS: 64 x 512 x 4 B =
 constexpr int kMaxRowsBwd = 16;   // backward stages 3 payloads per row
 // Batch rows per register tile RT (2 or 4) and row sets NRS (1 or 2 x 256 threads): see launch_gru.
 constexpr long kSpinTicks = 200000000L;  // 2 s of the 100 MHz wall clock
+constexpr long kSpinTicksFaultTest = 2000000L;   // 20 ms when the fault-injection hook is armed (tests)
 
 enum { GRU_OK = 0, GRU_TIMEOUT = 1 };
 
@@ -61,6 +64,8 @@ struct GruParams {
     gu32 *status;         // 0 ok / GRU_TIMEOUT
     int B, T, Hd;
     int NG, NGpad, NW, BL;  // groups, padded group count (blockIdx modulus), workgroups per group, rows per group
+    long spin_ticks;      // bound of every spin, in ticks of the 100 MHz wall clock
+    int fault_step;       // test hook (ddsp_gru_set_mode(2)): workgroup 0 withholds its publishes from this step on; -1 = off
 };
 
 // Gate non-linearities on the hardware exp2 / rcp (1 ulp each): |error| <= 2e-7, on the critical path of every step.
@@ -77,7 +82,8 @@ __device__ __forceinline__ unsigned long long pack_granule(unsigned epoch, float
 // flight per lane), and a batch whose tags all matched is not polled again.  Returns false (wave-uniform) on
 // timeout / abort.
 template <int RB, bool FIRST_LIGHT>
-__device__ __forceinline__ bool sweep_rows(gu64 *src, float *dst, int rows, int Hd, int HP, unsigned epoch, gu32 *status, int NT)
+__device__ __forceinline__ bool sweep_rows(gu64 *src, float *dst, int rows, int Hd, int HP, unsigned epoch, gu32 *status, int NT,
+                                           long spin_ticks)
 {
     const long t0 = wall_clock64();
     const int kc[2] = {(int)threadIdx.x, (int)threadIdx.x + NT};
@@ -94,7 +100,7 @@ __device__ __forceinline__ bool sweep_rows(gu64 *src, float *dst, int rows, int 
             const unsigned long long x = __hip_atomic_load(sentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all((unsigned)(x >> 32) == epoch)) break;
             if ((pass & 63) == 63) {
-                if (wall_clock64() - t0 > kSpinTicks) return false;
+                if (wall_clock64() - t0 > spin_ticks) return false;
                 if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -133,7 +139,7 @@ __device__ __forceinline__ bool sweep_rows(gu64 *src, float *dst, int rows, int 
         }
         if (todo == 0u) return true;
         if ((pass & 63) == 63) {
-            if (wall_clock64() - t0 > kSpinTicks) return false;
+            if (wall_clock64() - t0 > spin_ticks) return false;
             if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -198,13 +204,17 @@ __global__ void __launch_bounds__(256 * NRS, 1) gru_fwd_kernel(GruParams p)
         for (int g = 0; g < 3; ++g) pre[g] = p.gi[bt * G3 + g * Hd + u];
     }
 
+    const int fault_from = (p.fault_step >= 0 && blockIdx.x == 0) ? p.fault_step : 0x7fffffff;   // test hook: this workgroup stops publishing
+    int t_reached = 0;                                             // steps [0, t_reached) were completed by this workgroup
     for (int t = 0; t < p.T; ++t) {
         if (t > 0) {
-            const bool ok = sweep_rows<4, false>(xg + (size_t)((t - 1) & 1) * p.BL * HP, h_s, nrows, Hd, HP, (unsigned)t, p.status, 256 * NRS);
+            const bool ok = sweep_rows<4, false>(xg + (size_t)((t - 1) & 1) * p.BL * HP, h_s, nrows, Hd, HP, (unsigned)t, p.status, 256 * NRS,
+                                                 p.spin_ticks);
             if (!ok && (threadIdx.x & 63) == 0) *fail_s = 1;
         }
         __syncthreads();
         if (*fail_s) break;
+        t_reached = t + 1;
         for (int bt0 = rs * RT; bt0 < nrows; bt0 += RT * NRS) {
             const int bl = bt0 + ks;
             const bool mine = gate_lane && bl < nrows;
@@ -251,7 +261,7 @@ __global__ void __launch_bounds__(256 * NRS, 1) gru_fwd_kernel(GruParams p)
                 const float z = sigmoidf_(giz + (sz + bh[1]));
                 const float n = tanhf_(__fmaf_rn(r, ghn, gin));
                 const float hnew = __fmaf_rn(hp - n, z, n);
-                publish(xg + ((size_t)(t & 1) * p.BL + bl) * HP + u, (unsigned)t + 1u, hnew);
+                if (t < fault_from) publish(xg + ((size_t)(t & 1) * p.BL + bl) * HP + u, (unsigned)t + 1u, hnew);
                 p.y[bt * Hd + u] = hnew;
                 if (p.gates) {
                     p.gates[bt * G3 + u] = r;
@@ -265,11 +275,23 @@ __global__ void __launch_bounds__(256 * NRS, 1) gru_fwd_kernel(GruParams p)
         __syncthreads();  // h_s is rewritten by the next sweep
     }
     if (*fail_s) {
+        // Loud failure: everything this workgroup owns of the steps it did not complete becomes NaN (the buffers come from
+        // torch.empty: stale memory would otherwise flow into the weight gradients as finite garbage).
         if (threadIdx.x == 0) __hip_atomic_store(p.status, (unsigned)GRU_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int bl = ks; bl < nrows; bl += 16)
-            if (unit_ok && rs == 0) {
-                p.hT[(size_t)(row0 + bl) * Hd + u] = __builtin_nanf("");
-                p.y[((size_t)(row0 + bl) * p.T + (p.T - 1)) * Hd + u] = __builtin_nanf("");
+        const float nan = __builtin_nanf("");
+        if (unit_ok && rs == 0)
+            for (int bl = ks; bl < nrows; bl += 16) {
+                p.hT[(size_t)(row0 + bl) * Hd + u] = nan;
+                for (int t = t_reached; t < p.T; ++t) {
+                    const size_t bt = (size_t)(row0 + bl) * p.T + t;
+                    p.y[bt * Hd + u] = nan;
+                    if (p.gates) {
+                        p.gates[bt * G3 + u] = nan;
+                        p.gates[bt * G3 + Hd + u] = nan;
+                        p.gates[bt * G3 + 2 * Hd + u] = nan;
+                    }
+                    if (p.hn) p.hn[bt * Hd + u] = nan;
+                }
             }
     }
 }
@@ -360,6 +382,8 @@ __global__ void __launch_bounds__(256 * NRS, 1) gru_bwd_kernel(GruParams p)
     derive();
     if (p.T > 1) fetch(p.T - 2);
 
+    const int fault_from = (p.fault_step >= 0 && blockIdx.x == 0) ? p.fault_step : 0x7fffffff;   // test hook: this workgroup stops publishing
+    int s_reached = 0;                                             // steps [0, s_reached) (t = T-1-s) wrote their gradients
     for (int s = 0; s < p.T; ++s) {
         const int t = p.T - 1 - s;
         const unsigned epoch = (unsigned)s + 1u;
@@ -376,9 +400,11 @@ __global__ void __launch_bounds__(256 * NRS, 1) gru_bwd_kernel(GruParams p)
                 const float dr_pre = dh * f_r[q], dz_pre = dh * f_z[q], dhn = dh * f_hn[q], dn_pre = dh * f_n[q];
                 direct[q] = dh * f_dir[q];
                 gu64 *gdst = slot + (size_t)bl * 3 * HP + k;
-                publish(gdst, epoch, dr_pre);
-                publish(gdst + HP, epoch, dz_pre);
-                publish(gdst + 2 * HP, epoch, dhn);
+                if (s < fault_from) {
+                    publish(gdst, epoch, dr_pre);
+                    publish(gdst + HP, epoch, dz_pre);
+                    publish(gdst + 2 * HP, epoch, dhn);
+                }
                 p.d_gi[bt * G3 + k] = dr_pre;
                 p.d_gi[bt * G3 + Hd + k] = dz_pre;
                 p.d_gi[bt * G3 + 2 * Hd + k] = dn_pre;
@@ -387,9 +413,10 @@ __global__ void __launch_bounds__(256 * NRS, 1) gru_bwd_kernel(GruParams p)
                 p.d_gh[bt * G3 + 2 * Hd + k] = dhn;
             }
         }
+        s_reached = s + 1;
         // 2. the group's gate gradients -> LDS  (rows of 3 payloads: treated as 3*nrows rows of width Hd)
         {
-            const bool ok = sweep_rows<12, NRS == 1>(slot, d_s, 3 * nrows, Hd, HP, epoch, p.status, 256 * NRS);
+            const bool ok = sweep_rows<12, NRS == 1>(slot, d_s, 3 * nrows, Hd, HP, epoch, p.status, 256 * NRS, p.spin_ticks);
             if (!ok && (threadIdx.x & 63) == 0) *fail_s = 1;
         }
         __syncthreads();
@@ -429,9 +456,24 @@ __global__ void __launch_bounds__(256 * NRS, 1) gru_bwd_kernel(GruParams p)
         __syncthreads();  // d_s is rewritten by the next sweep
     }
     if (*fail_s) {
+        // Loud failure: dh0 and the gate gradients of every step this workgroup did not reach become NaN, so the weight
+        // gradients (d_gh^T h, sum d_gh, d_gi through autograd) are NaN instead of stale memory.
         if (threadIdx.x == 0) __hip_atomic_store(p.status, (unsigned)GRU_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float nan = __builtin_nanf("");
 #pragma unroll
-        for (int q = 0; q < Q; ++q) carry[q] = __builtin_nanf("");
+        for (int q = 0; q < Q; ++q) {
+            carry[q] = nan;
+            const int bl = (q * NRS + rs) * RT + us;
+            if (gate_lane && bl < nrows)
+                for (int s = s_reached; s < p.T; ++s) {
+                    const size_t bt = (size_t)(row0 + bl) * p.T + (p.T - 1 - s);
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        p.d_gi[bt * G3 + g * Hd + k] = nan;
+                        p.d_gh[bt * G3 + g * Hd + k] = nan;
+                    }
+                }
+        }
     }
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -442,7 +484,21 @@ __global__ void __launch_bounds__(256 * NRS, 1) gru_bwd_kernel(GruParams p)
 
 // ---- host side ----------------------------------------------------------------------------------------------
 struct GruPlan { int KP, HP, NW, NG, NGpad, BL; };
-int g_gru_mode = 0;  // ddsp_gru_set_mode
+int g_gru_mode = 0;        // ddsp_gru_set_mode: bit 0 = spread placement, bit 1 = fault injection (tests)
+int g_gru_fault_step = 0;  // with bit 1: workgroup 0 withholds its publishes from this step on
+
+// Co-residency guard, part 2: two persistent launches that each want one workgroup per CU must not run at the same time
+// on one device (two streams of a process could each get part of the CUs and starve each other into the timeout).  Every
+// launch of this process therefore waits for the previous recurrence launch on the same device (an event wait on the
+// launching stream -- device-side ordering, the host never blocks) and records its own completion.  Launches into a
+// stream that is being captured are ordered by the graph itself and skip the event (waiting on an event recorded
+// outside the capture is not capturable).  Other PROCESSES sharing the GPU are outside this guard: see DESIGN.md §9a.
+struct DeviceGate {
+    std::mutex mu;
+    hipEvent_t last = nullptr;
+    bool armed = false;
+};
+DeviceGate g_gate[64];
 
 // Groups / rows per group for a [B, Hd] problem on a device with `cus` compute units; false if it does not fit.
 // `spread` (test hook): an odd blockIdx modulus NG | 1, which deals every group's workgroups over all XCDs.
@@ -482,11 +538,38 @@ int device_cus(int *cus)
 
 size_t xchg_bytes(const GruPlan &pl, int payloads) { return (size_t)pl.NG * 2 * pl.BL * payloads * pl.HP * sizeof(unsigned long long); }
 
+// Co-residency guard, part 1: every workgroup of the grid spins on its peers, so the whole grid has to be resident at
+// once.  The grid is sized one workgroup per CU; what the runtime says a CU admits of this kernel (registers, LDS,
+// threads) x the CU count must cover it, otherwise the launch is refused (DDSP_ERANGE) instead of stalling into the
+// timeout.  Queried once per kernel instantiation, LDS size class and device.
+template <typename K>
+hipError_t check_resident(K kernel, int threads, size_t lds, unsigned grid, int (&cache)[64])
+{
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (device_cus(&cus)) return hipErrorInvalidDevice;
+    int &per_cu = cache[dev & 63];
+    if (per_cu == 0) {
+        int n = 0;
+        // asked with the largest LDS footprint any plan of this instantiation uses, so that the answer can be cached
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds);
+        if (e != hipSuccess) return e;
+        per_cu = n > 0 ? n : -1;
+    }
+    if (per_cu < 0 || (unsigned long long)per_cu * (unsigned)cus < grid) return hipErrorCooperativeLaunchTooLarge;
+    return hipSuccess;
+}
+
 template <int KP, int RT, int NRS>
 hipError_t launch_fwd(const GruParams &p, size_t lds, hipStream_t s)
 {
     static bool attr[64] = {};
-    const hipError_t e = ddsp_allow_big_lds((const void *)gru_fwd_kernel<KP, RT, NRS>, attr);
+    static int resident[64] = {};
+    hipError_t e = ddsp_allow_big_lds((const void *)gru_fwd_kernel<KP, RT, NRS>, attr);
+    if (e != hipSuccess) return e;
+    e = check_resident(gru_fwd_kernel<KP, RT, NRS>, 256 * NRS, sizeof(float) * ((size_t)kMaxRows * 16 * KP + 4),
+                       (unsigned)(p.NGpad * p.NW), resident);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((gru_fwd_kernel<KP, RT, NRS>), dim3((unsigned)(p.NGpad * p.NW)), dim3(256 * NRS), lds, s, p);
     return hipGetLastError();
@@ -496,7 +579,11 @@ template <int KP, int RT, int NRS>
 hipError_t launch_bwd(const GruParams &p, size_t lds, hipStream_t s)
 {
     static bool attr[64] = {};
-    const hipError_t e = ddsp_allow_big_lds((const void *)gru_bwd_kernel<KP, RT, NRS>, attr);
+    static int resident[64] = {};
+    hipError_t e = ddsp_allow_big_lds((const void *)gru_bwd_kernel<KP, RT, NRS>, attr);
+    if (e != hipSuccess) return e;
+    e = check_resident(gru_bwd_kernel<KP, RT, NRS>, 256 * NRS, sizeof(float) * ((size_t)kMaxRowsBwd * 3 * 16 * KP + 4),
+                       (unsigned)(p.NGpad * p.NW), resident);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((gru_bwd_kernel<KP, RT, NRS>), dim3((unsigned)(p.NGpad * p.NW)), dim3(256 * NRS), lds, s, p);
     return hipGetLastError();
@@ -523,10 +610,32 @@ int run_gru(GruParams &p, void *scratch, bool backward, hipStream_t s)
     if (!plan_gru(p.B, p.Hd, cus, backward ? kMaxRowsBwd : kMaxRows, (g_gru_mode & 1) != 0, &pl)) return DDSP_ERANGE;
     p.NG = pl.NG; p.NGpad = pl.NGpad; p.NW = pl.NW; p.BL = pl.BL;
     const int payloads = backward ? 3 : 1;
+    const bool inject = (g_gru_mode & 2) != 0;
+    p.spin_ticks = inject ? kSpinTicksFaultTest : kSpinTicks;
+    p.fault_step = inject ? g_gru_fault_step : -1;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    e = hipStreamIsCapturing(s, &capturing);
+    if (e != hipSuccess) return (int)e;
+    DeviceGate &gate = g_gate[dev & 63];
+    std::unique_lock<std::mutex> lock(gate.mu, std::defer_lock);
+    if (capturing == hipStreamCaptureStatusNone) {
+        lock.lock();      // launch order == event order, also with several host threads
+        if (!gate.last) {
+            e = hipEventCreateWithFlags(&gate.last, hipEventDisableTiming);
+            if (e != hipSuccess) return (int)e;
+        }
+        if (gate.armed) {
+            e = hipStreamWaitEvent(s, gate.last, 0);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
     // scratch: [status: 256 B][granules]; every polled word is zeroed before EVERY launch (epochs restart at 1)
     p.status = (gu32 *)scratch;
     p.xchg = (gu64 *)((char *)scratch + 256);
-    hipError_t e = hipMemsetAsync(scratch, 0, 256 + xchg_bytes(pl, payloads), s);
+    e = hipMemsetAsync(scratch, 0, 256 + xchg_bytes(pl, payloads), s);
     if (e != hipSuccess) return (int)e;
     const int RT = (backward && pl.BL > 2 && pl.BL <= 4) ? 4 : 2;
     const int NRS = (pl.BL <= 2 || RT == 4) ? 1 : 2;
@@ -537,6 +646,11 @@ int run_gru(GruParams &p, void *scratch, bool backward, hipStream_t s)
         case 8: e = launch_gru<8>(p, backward, RT, NRS, lds, s); break;
         case 16: e = launch_gru<16>(p, backward, RT, NRS, lds, s); break;
         default: e = launch_gru<32>(p, backward, RT, NRS, lds, s); break;
+    }
+    if (e == hipErrorCooperativeLaunchTooLarge) return DDSP_ERANGE;   // the grid cannot be resident at once on this device
+    if (e == hipSuccess && capturing == hipStreamCaptureStatusNone) {
+        e = hipEventRecord(gate.last, s);
+        gate.armed = e == hipSuccess;
     }
     return (int)e;
 }
@@ -589,8 +703,15 @@ extern "C" int ddsp_gru_backward(const float *dy, const float *dhT, const float 
 
 extern "C" int ddsp_gru_set_mode(int mode)
 {
-    if (mode < 0 || mode > 1) return DDSP_ERANGE;
+    if (mode < 0 || mode > 3) return DDSP_ERANGE;
     g_gru_mode = mode;
+    return 0;
+}
+
+extern "C" int ddsp_gru_set_fault_step(int step)
+{
+    if (step < 0) return DDSP_ERANGE;
+    g_gru_fault_step = step;
     return 0;
 }
 

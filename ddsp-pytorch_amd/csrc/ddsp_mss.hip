@@ -74,8 +74,12 @@ extern "C" size_t ddsp_spectral_loss_scratch_bytes(void) { return sizeof(float) 
 extern "C" int ddsp_spectral_loss(const float *pred_ri, const float *true_ri, float *grad_ri, void *scratch, float *out3,
                                   long n_bins, float alpha, float eps, void *stream)
 {
-    if (!pred_ri || !true_ri || !scratch || !out3 || n_bins <= 0) return DDSP_EINVAL;
     if (!(eps > 0.0f)) return DDSP_EINVAL;
+    if (n_bins == 0) {   // an empty shard: the mean over no bins is reported as 0 (and there is no gradient to write)
+        if (!out3) return DDSP_EINVAL;
+        return (int)hipMemsetAsync(out3, 0, 3 * sizeof(float), (hipStream_t)stream);
+    }
+    if (!pred_ri || !true_ri || !scratch || !out3 || n_bins < 0) return DDSP_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     long want = (n_bins + 255) / 256;
     const int blocks = (int)(want < kBlocks ? want : kBlocks);

@@ -91,7 +91,10 @@ class FilteredNoise(nn.Module):
             raise ValueError("rng must be 'host' (torch CPU generator, reference-compatible) or 'device' (Philox)")
         self.rng = rng
         self.seed = seed
-        self._calls = 0
+        # Philox offset of the next in-kernel draw: advanced by what each call consumes (B*T*ceil(hop/4) counters), so
+        # calls of different shapes (a last partial batch, train/eval switches) never overlap earlier draws.  Not part of
+        # the state_dict (the reference has no such state): a resumed run that must not replay the stream passes a new `seed`.
+        self._offset = 0
 
     def forward(self, x, noise=None, out=None):
         """`out` (inference only): accumulate the noise into this [B, T*hop] buffer instead of returning a new one."""
@@ -101,9 +104,8 @@ class FilteredNoise(nn.Module):
             noise = torch.rand(B, T, self.block_size)  # :44-48: CPU global generator, same shape and order
         offset = 0
         if noise is None:
-            quads = (self.block_size + 3) // 4
-            offset = self._calls * B * T * quads
-            self._calls += 1
+            offset = self._offset
+            self._offset += B * T * ((self.block_size + 3) // 4)
         if torch.is_grad_enabled() and param.requires_grad:
             if not param.is_cuda:
                 raise _lib.DdspHipError("FilteredNoise runs on the GPU only (no CPU fallback): move the controls to cuda")

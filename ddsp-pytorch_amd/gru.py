@@ -3,8 +3,8 @@
 The reference's control network runs `nn.GRU(2*width, units, layers, batch_first=True)` over the whole clip
 (model/autoencoder/decoder.py:60-65, :91) and over one callback's frames with a carried state in the live path
 (:91 via `forward_live` :139-147).  This class IS an `nn.GRU` (same parameters `weight_ih_l0 / weight_hh_l0 /
-bias_ih_l0 / bias_hh_l0`, so the reference's checkpoints load unchanged); for CUDA inputs of a single-layer,
-unidirectional GRU with hidden size <= 512 it computes
+bias_ih_l0 / bias_hh_l0`, so the reference's checkpoints load unchanged); for CUDA inputs of a unidirectional GRU
+with hidden size <= 512 (any number of stacked layers, one recurrence launch per layer) it computes
 
     gi = x W_ih^T + b_ih                       one library GEMM (differentiated by autograd as usual)
     y, h_T = recurrence(gi, W_hh, b_hh, h_0)   csrc/ddsp_gru.hip, forward and backward
@@ -16,6 +16,7 @@ library raises `DdspHipError` -- there is no silent fallback.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -24,8 +25,29 @@ import torch.nn.functional as F
 from . import _lib
 
 
+_debug = os.environ.get("DDSP_GRU_DEBUG", "0") not in ("", "0")
+
+
+def set_debug(flag: bool) -> bool:
+    """Debug mode: after every recurrence launch the host reads the launch's status word (one synchronisation per
+    launch) and raises `DdspHipError` if a workgroup gave up waiting for its peers.  Without it a failed launch is
+    still loud -- every output of the steps it did not finish is NaN -- but asynchronous.  Returns the previous mode."""
+    global _debug
+    old, _debug = _debug, bool(flag)
+    return old
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
+
+
+def _raise_on_timeout(scratches, what: str) -> None:
+    for s in scratches:
+        if gru_status(s) != 0:
+            raise _lib.DdspHipError(
+                f"{what}: a workgroup of the persistent GRU launch timed out waiting for its peers (status 1). The launch needs "
+                "its whole grid resident: another persistent launch from a different process was probably holding the GPU's "
+                "compute units. The outputs of the unfinished steps are NaN.")
 
 
 def gru_forward(gi, w_hh, b_hh, h0, save: bool, scratch_out: list | None = None):
@@ -95,7 +117,10 @@ class _Recurrence(torch.autograd.Function):
         b = None if b_hh is None else b_hh.detach().contiguous().float()
         h = None if h0 is None else h0.detach().contiguous().float()
         need = any(ctx.needs_input_grad)
-        y, hT, gates, hn = gru_forward(gi.detach(), w, b, h, save=need)
+        launched = [] if _debug else None
+        y, hT, gates, hn = gru_forward(gi.detach(), w, b, h, save=need, scratch_out=launched)
+        if _debug:
+            _raise_on_timeout(launched, "ddsp_gru_forward")
         if need:
             ctx.save_for_backward(w, h, y, gates, hn)
             ctx.has_bias = b is not None
@@ -107,7 +132,10 @@ class _Recurrence(torch.autograd.Function):
         B, T, Hd = y.shape
         dy = torch.zeros_like(y) if dy is None else dy.contiguous().float()
         dhT = None if dhT is None else dhT.contiguous().float()
-        d_gi, d_gh, dh0 = gru_backward(dy, dhT, w, h0, y, gates, hn)
+        launched = [] if _debug else None
+        d_gi, d_gh, dh0 = gru_backward(dy, dhT, w, h0, y, gates, hn, scratch_out=launched)
+        if _debug:
+            _raise_on_timeout(launched, "ddsp_gru_backward")
         dw = db = None
         if ctx.needs_input_grad[1]:
             first = h0 if h0 is not None else torch.zeros((B, Hd), device=y.device, dtype=y.dtype)
@@ -121,23 +149,27 @@ class _Recurrence(torch.autograd.Function):
 class GRU(nn.GRU):
     """Drop-in `nn.GRU`; see the module docstring for when the HIP recurrence runs."""
 
-    def _hip_eligible(self, x: torch.Tensor) -> bool:
-        return (x.is_cuda and x.dim() == 3 and self.num_layers == 1 and not self.bidirectional and self.proj_size == 0
+    def _hip_eligible(self, x) -> bool:
+        # anything that is not a dense batched CUDA tensor (PackedSequence, unbatched 2-D input, CPU) is nn.GRU's business
+        return (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 3 and not self.bidirectional and self.proj_size == 0
                 and self.hidden_size <= 512 and x.dtype == torch.float32)
 
     def forward(self, input, hx=None):  # noqa: A002 (torch's argument name)
         if not self._hip_eligible(input):
             return super().forward(input, hx)
         x = input if self.batch_first else input.transpose(0, 1)
-        b_ih = getattr(self, "bias_ih_l0", None) if self.bias else None
-        b_hh = getattr(self, "bias_hh_l0", None) if self.bias else None
-        gi = F.linear(x, self.weight_ih_l0, b_ih)
-        h0 = None
-        if hx is not None:
-            if hx.dim() != 3 or hx.shape[0] != 1 or hx.shape[1] != x.shape[0] or hx.shape[2] != self.hidden_size:
-                raise RuntimeError(f"Expected hidden size (1, {x.shape[0]}, {self.hidden_size}), got {list(hx.shape)}")
-            h0 = hx[0]
-        y, hT = _Recurrence.apply(gi, self.weight_hh_l0, b_hh, h0)
+        if hx is not None and (hx.dim() != 3 or hx.shape[0] != self.num_layers or hx.shape[1] != x.shape[0]
+                               or hx.shape[2] != self.hidden_size):
+            raise RuntimeError(f"Expected hidden size ({self.num_layers}, {x.shape[0]}, {self.hidden_size}), got {list(hx.shape)}")
+        finals = []
+        for layer in range(self.num_layers):     # decoder.py:60-65 `num_layers=conf.decoder_gru_layers`: stacked, layer by layer
+            b_ih = getattr(self, f"bias_ih_l{layer}", None) if self.bias else None
+            b_hh = getattr(self, f"bias_hh_l{layer}", None) if self.bias else None
+            gi = F.linear(x, getattr(self, f"weight_ih_l{layer}"), b_ih)
+            x, hT = _Recurrence.apply(gi, getattr(self, f"weight_hh_l{layer}"), b_hh, None if hx is None else hx[layer])
+            finals.append(hT)
+            if self.dropout > 0 and self.training and layer + 1 < self.num_layers:
+                x = F.dropout(x, self.dropout, True)
         if not self.batch_first:
-            y = y.transpose(0, 1)
-        return y, hT.unsqueeze(0)
+            x = x.transpose(0, 1)
+        return x, torch.stack(finals, dim=0)

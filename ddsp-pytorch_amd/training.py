@@ -127,9 +127,18 @@ def train_step(model: nn.Module, loss_fn: nn.Module, optimizer: torch.optim.Opti
     """One optimisation step of `Zak.training_step` (train/train.py:32-37) + Adam, data-parallel.
     `batch` is this rank's shard: a dict with the controller inputs and the target `audio`."""
     optimizer.zero_grad(set_to_none=True)
-    audio = model(batch)
-    loss = loss_fn(audio, batch)
-    loss.backward()
+    rows = next((v.shape[0] for v in batch.values() if torch.is_tensor(v)), 0) if isinstance(batch, dict) else len(batch)
+    if rows == 0:
+        # an empty shard (global batch < world size): nothing to synthesise, but this rank still takes part in the
+        # collective -- with zero gradients -- so that the replicas stay in lock-step
+        params = [p for p in model.parameters() if p.requires_grad]
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        loss = torch.zeros((), device=params[0].device if params else "cpu")
+    else:
+        audio = model(batch)
+        loss = loss_fn(audio, batch)
+        loss.backward()
     nbytes = allreduce_gradients([p for p in model.parameters() if p.requires_grad], group)
     optimizer.step()
     return loss.detach(), nbytes

@@ -133,7 +133,10 @@ int ddsp_profile_read(int *kernel_ids, float *ms, int cap);
  *                      -> d_gi [B,T,3Hd] (gradient of gi), d_gh [B,T,3Hd] (gradient of W_hh h + b_hh), dh0 [B,Hd]
  *   ddsp_gru_status    HOST int*: 0, or 1 if a workgroup gave up waiting for its peers (outputs are then NaN);
  *                      synchronous copy, tests / diagnostics only
- * The grid is sized to be co-resident (one workgroup per CU); every wait inside is bounded (2 s).
+ * The grid is sized to be co-resident (one workgroup per CU) and checked against the runtime's occupancy answer
+ * (DDSP_ERANGE if it could not be); launches of one process on one device are ordered behind each other on the device
+ * (event wait on the launching stream; not inside a stream capture); every wait inside is bounded (2 s): on a time-out
+ * the status word is raised and every output of the unfinished steps is NaN.
  */
 size_t ddsp_gru_scratch_bytes(int B, int Hd);
 int ddsp_gru_max_batch(int Hd, int backward);
@@ -143,9 +146,12 @@ int ddsp_gru_backward(const float *dy, const float *dhT, const float *w_hh, cons
                       const float *gates, const float *hn, float *d_gi, float *d_gh, float *dh0, void *scratch,
                       int B, int T, int Hd, void *stream);
 int ddsp_gru_status(const void *scratch, int *status_host);
-/* Test hook (process-global): 1 deals every group's workgroups over all XCDs (odd blockIdx modulus) instead of keeping
- * a group on one XCD; 0 restores the default.  Bitwise the same results either way (placement only changes speed). */
+/* Test hooks (process-global bit mask; 0 restores the default).  Bit 0: deal every group's workgroups over all XCDs (odd
+ * blockIdx modulus) instead of keeping a group on one XCD -- bitwise the same results either way (placement only changes
+ * speed).  Bit 1: fault injection -- workgroup 0 withholds its publishes from step ddsp_gru_set_fault_step() on and the
+ * spin bound drops to 20 ms, so that the time-out path (status word, NaN in every unfinished output) can be tested. */
 int ddsp_gru_set_mode(int mode);
+int ddsp_gru_set_fault_step(int step);
 
 /*
  * One scale of the multi-scale spectral loss (loss/mss_loss.py:11-33: L1 of the power spectrograms + alpha * L1 of their

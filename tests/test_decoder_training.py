@@ -126,6 +126,39 @@ def test_data_parallel_step_two_ranks_equals_single(tmp_path):
     assert max(float((ref[k] - sd0[k]).abs().max()) for k in ref) <= 2e-5
 
 
+def test_train_step_with_an_empty_shard():
+    """shard_rows hands a rank zero rows when the batch is smaller than the world: the step must not fail and leaves the
+    parameters where zero gradients leave them (the rank still joins the all-reduce)."""
+    torch.manual_seed(5)
+    model = CpuSurrogate()
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    full = make_batch(3, 4)
+    lo, hi = ddsp.sharding.shard_rows(1, 1, 2)                   # rank 1 of 2 on a 1-row batch: [1, 1)
+    assert lo == hi
+    loss, nbytes = ddsp.train_step(model, ddsp.MSSLoss((128, 64)), opt, {k: v[lo:hi] for k, v in full.items()})
+    assert float(loss) == 0.0 and nbytes == 4 * sum(p.numel() for p in model.parameters())
+    assert all(torch.equal(before[k], v) for k, v in model.state_dict().items())
+
+
+@pytest.mark.gpu
+def test_empty_rows_through_the_fused_controller_passes():
+    """Zero rows through Linear -> fused LayerNorm+LeakyReLU -> fused head non-linearity, forward and backward: empty
+    outputs, zero parameter gradients (ddsp_ln_lrelu_backward / ddsp_spectral_loss accept empty inputs like the synth
+    entry points do)."""
+    from ddsp_pytorch_amd.decoder import _dense_stack, _run_stack, scaled_sigmoid
+    from ddsp_pytorch_amd.training import _FusedSpectralL1
+    stack = _dense_stack(3, 256, 2).cuda()
+    x = torch.zeros(0, 5, 3, device="cuda", requires_grad=True)
+    y = scaled_sigmoid(_run_stack(stack, x))
+    assert y.shape == (0, 5, 256)
+    y.sum().backward()
+    for p in stack.parameters():
+        assert p.grad is not None and float(p.grad.abs().max()) == 0.0
+    e = torch.zeros(0, 2, device="cuda")
+    assert float(_FusedSpectralL1.apply(e, e, 1.0, 1e-7)) == 0.0
+
+
 @pytest.mark.gpu
 def test_decoder_forward_live_and_train_step_gpu():
     class Conf:

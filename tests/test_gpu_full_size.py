@@ -140,3 +140,98 @@ def test_graphed_synth_offline_and_live():
         ddsp.noise_forward(x2["H"], 128, seed=3, offset=call * 4 * 32, out=ref, accumulate=True)
         assert torch.equal(gl(x2), ref)
         assert torch.equal(gl.state, osc.last_phases.data)
+
+
+def test_cfg3_whole_workload():
+    """BASELINE.json configs[2] as written: batch 512, 48 kHz, hop 512, 375 frames (4 s), 200 harmonics, 257 noise bands --
+    the K=25/G=8 oscillator tiling, 4x longer phase drift than the 1 s fixture G4, 16-frames-per-workgroup noise tiles.
+    The oracle does three whole rows in seconds; the other 509 rows are covered by size-independent properties."""
+    shape = syn.CFG3
+    ctl, x = controls(shape, 1003)
+    y, _, _ = ddsp.osc_forward(x["f0"], x["c"], x["a"], shape.hop, shape.sample_rate)
+    assert y.shape == (512, 192000) and bool(torch.isfinite(y).all())
+    y2, _, _ = ddsp.osc_forward(x["f0"], x["c"], x["a"], shape.hop, shape.sample_rate)
+    assert torch.equal(y, y2)                                                    # determinism
+    perm = torch.randperm(shape.batch, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+    yp, _, _ = ddsp.osc_forward(x["f0"][perm], x["c"][perm], x["a"][perm], shape.hop, shape.sample_rate)
+    assert torch.equal(yp, y[perm])                                              # row permutation equivariance, bit for bit
+    del yp, y2
+    yl, _, _ = ddsp.osc_forward(x["f0"], x["c"], 2.0 * x["a"], shape.hop, shape.sample_rate)
+    assert torch.equal(yl, 2.0 * y)                                              # loudness linearity (power-of-two: exact)
+    del yl
+    rows = [0, 255, 511]
+    ref = oracle.osc_forward(ctl["f0"][rows], ctl["c"][rows], ctl["a"][rows], shape.hop, shape.sample_rate)
+    assert np.max(np.abs(y[rows].cpu().numpy() - ref)) <= 1e-5                   # three whole 4 s rows against the oracle
+    # noise: the whole batch with the in-kernel draw (determinism, H linearity), three rows with an injected draw vs the oracle
+    n1 = ddsp.noise_forward(x["H"], shape.hop, seed=9)
+    assert n1.shape == y.shape and bool(torch.isfinite(n1).all())
+    assert torch.equal(n1, ddsp.noise_forward(x["H"], shape.hop, seed=9))
+    n2 = ddsp.noise_forward(2.0 * x["H"], shape.hop, seed=9)
+    assert torch.equal(n2, 2.0 * n1)
+    del n2
+    u = np.random.default_rng(33).random((3, shape.frames, shape.hop), dtype=np.float32)
+    hrows = x["H"][rows].contiguous()
+    got = ddsp.noise_forward(hrows, shape.hop, uniform=torch.from_numpy(u).cuda())
+    nref = oracle.noise_forward(ctl["H"][rows], u, shape.hop)
+    assert np.max(np.abs(got.cpu().numpy() - nref)) <= 2e-6 * max(1.0, float(np.max(np.abs(nref))))
+    # the fused epilogue on the full buffer: harmonics + noise accumulated in place == the two parts added
+    total = y.clone()
+    ddsp.noise_forward(x["H"], shape.hop, seed=9, out=total, accumulate=True)
+    assert float((total - (y + n1)).abs().max()) <= 1e-6
+
+
+def test_cfg5_per_gpu_train_step_full_shape():
+    """BASELINE.json configs[4], one GPU's share: batch 32, 500 frames (4 s at 16 kHz, hop 128), 100 harmonics, 65 noise bands,
+    controller widths 512 (GRU 8 groups x 32 workgroups).  One whole `train_step` (decoder -> HIP synth -> reverb -> 6-scale
+    spectral loss -> backward -> Adam) in GRU debug mode (every recurrence launch's status word is checked: a time-out
+    raises), finite loss and gradients, and the batch gradient equals the mean of the two half-batch gradients."""
+    from ddsp_pytorch_amd import gru as gru_mod
+
+    class Conf:
+        n_harmonics, n_noise_filters, sample_rate, hop_length = 100, 65, 16000, 128
+        decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 512, 3, 512, 1
+
+    B, T = 32, 500
+    torch.manual_seed(0)
+    model = ddsp.Decoder(Conf, noise_rng="device", seed=1).cuda()
+    with torch.no_grad():
+        model.reverb.wet.fill_(-1.0)
+    loss_fn = ddsp.MSSLoss().cuda()
+    rng = np.random.default_rng(2000)
+    batch = {"normalized_cents": torch.from_numpy(rng.uniform(0, 1, (B, T, 1)).astype(np.float32)).cuda(),
+             "loudness": torch.from_numpy(rng.uniform(-1, 1, (B, T, 1)).astype(np.float32)).cuda(),
+             "f0": torch.from_numpy(syn.musical_f0(rng, B, T)).cuda(),
+             "audio": torch.from_numpy((0.1 * rng.standard_normal((B, T * 128))).astype(np.float32)).cuda()}
+    draw = torch.from_numpy(rng.random((B, T, 128), dtype=np.float32)).cuda()
+    plain = model.noise.forward
+    rows = [slice(0, B)]
+    model.noise.forward = lambda x, noise=None, out=None: plain(x, noise=draw[rows[0]], out=out)   # the draw travels with the rows
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def grads(sl):
+        rows[0] = sl
+        for p in params:
+            p.grad = None
+        loss = loss_fn(model({k: v[sl] for k, v in batch.items()}), batch["audio"][sl])
+        loss.backward()
+        return float(loss), [p.grad.detach().clone() for p in params]
+
+    old = gru_mod.set_debug(True)
+    try:
+        l_all, g_all = grads(slice(0, B))
+        l_a, g_a = grads(slice(0, B // 2))
+        l_b, g_b = grads(slice(B // 2, B))
+        assert np.isfinite(l_all) and all(bool(torch.isfinite(g).all()) for g in g_all)
+        assert abs(0.5 * (l_a + l_b) - l_all) <= 1e-5 * abs(l_all)
+        worst = 0.0
+        for ga, gb, gf in zip(g_a, g_b, g_all):
+            worst = max(worst, float((0.5 * (ga + gb) - gf).abs().max()) / (float(gf.abs().max()) + 1e-12))
+        assert worst <= 1e-4, worst        # mean-reduced loss: batch gradient = mean of equal halves' gradients (fp32 reductions)
+        # and the optimiser step itself on the whole shape
+        rows[0] = slice(0, B)
+        opt = torch.optim.Adam(params, lr=1e-3)
+        l0, nbytes = ddsp.train_step(model, loss_fn, opt, batch)
+        l1, _ = ddsp.train_step(model, loss_fn, opt, batch)
+        assert nbytes == 4 * sum(p.numel() for p in params) and np.isfinite(float(l0)) and np.isfinite(float(l1))
+    finally:
+        gru_mod.set_debug(old)

@@ -1,0 +1,107 @@
+"""Two ranks of the HIP path on the GPU box: each rank is a fresh python process (tests/two_rank_worker.py),
+both on cuda:0, gloo rendezvous on 127.0.0.1 -- the one-GPU rehearsal of `bench.py --gpus 2` as a committed test.
+
+  * batch-sharded synthesis: concatenated shards == the unsharded run, bit for bit (rows are independent, no collective);
+  * data-parallel training: replicas stay bit-identical after two `train_step`s with one flat gradient all-reduce, and equal
+    the single-process step on the whole batch (mean-reduced loss: the mean of equal shards' gradients is the batch gradient);
+  * `python bench.py --gpus 2` without a launcher starts its own ranks and prints one JSON line with n_gpus = 2.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import ddsp_pytorch_amd as ddsp  # noqa: E402
+import two_rank_common as common  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_ranks(out_dir, world=2):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_rank_worker.py"), str(out_dir)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(out)
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-4000:]
+
+
+@pytest.fixture(scope="module")
+def rank_outputs(tmp_path_factory):
+    out = tmp_path_factory.mktemp("two_ranks")
+    _run_ranks(out)
+    return out
+
+
+def test_sharded_synthesis_equals_unsharded_bitwise(rank_outputs):
+    ctl, uniform = common.synth_problem()
+    x = {k: torch.from_numpy(v).cuda() for k, v in ctl.items()}
+    full = common.synthesize(ddsp, x, torch.from_numpy(uniform).cuda()).cpu()
+    parts = torch.cat([torch.load(rank_outputs / f"y{r}.pt", weights_only=True) for r in range(2)], dim=0)
+    assert parts.shape == full.shape == (common.SYNTH.batch, common.SYNTH.samples)
+    assert torch.equal(parts, full)
+
+
+def test_data_parallel_replicas_lock_step_and_equal_single_process(rank_outputs):
+    sd0 = torch.load(rank_outputs / "sd0.pt", weights_only=True)
+    sd1 = torch.load(rank_outputs / "sd1.pt", weights_only=True)
+    assert all(torch.equal(sd0[k], sd1[k]) for k in sd0)          # one all-reduced bucket -> identical updates
+    model, loss_fn, opt = common.make_trainer(ddsp)
+    init = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    full = {k: v.cuda() for k, v in common.train_batch().items()}
+    losses = [float(ddsp.train_step(model, loss_fn, opt, full)[0]) for _ in range(common.TRAIN_STEPS)]
+    ref = {k: v.cpu() for k, v in model.state_dict().items()}
+    moved = 0
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        d_ref, d_got = ref[k] - init[k], sd0[k] - init[k]
+        scale = float(d_ref.abs().max())
+        moved += scale > 0
+        assert float((d_got - d_ref).abs().max()) <= 2e-4 * scale + 1e-9, k
+    assert moved >= 30                                             # every trainable tensor received a gradient
+    # the ranks' mean loss is the batch loss (equal shards)
+    l0 = torch.load(rank_outputs / "loss0.pt", weights_only=True)
+    l1 = torch.load(rank_outputs / "loss1.pt", weights_only=True)
+    assert abs(0.5 * float(l0[0] + l1[0]) - losses[0]) <= 1e-4 * abs(losses[0])
+
+
+def test_bench_self_launches_two_ranks():
+    """bench.py --gpus 2 with no WORLD_SIZE: the parent (GPU-free) starts two ranks under torch.distributed.run, both on
+    this box's one GPU (--one-device, gloo), small batch; rank 0 prints the one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "16", "--backend", "gloo", "--one-device"], env=env, capture_output=True, text=True,
+                       timeout=420)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["value"] > 0 and abs(line["samples_per_sec_per_gpu"] * 2 - line["value"]) <= 1e-6 * line["value"]
+    assert "roofline" in line and "cpu_baseline" not in line      # the CPU baseline is an N = 1 figure

@@ -194,3 +194,112 @@ def test_gru_recurrence_is_graph_capturable():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(y, new_y)
+
+
+@pytest.mark.gpu
+def test_gru_two_streams_concurrently_are_serialised_and_correct():
+    """Co-residency guard: two persistent launches want one workgroup per CU each, so launches of one process
+    on one device are ordered behind each other on the device (event wait on the launching stream).  Forward + backward
+    issued from two streams at the same time at the training shape: correct, finite, status 0, bitwise equal to the
+    one-stream results."""
+    torch.manual_seed(21)
+    B, T, hd = 32, 120, 512
+    probs = []
+    for i in range(2):
+        probs.append(dict(gi=torch.randn(B, T, 3 * hd, device="cuda"), w=torch.randn(3 * hd, hd, device="cuda") * 0.05,
+                          b=torch.randn(3 * hd, device="cuda") * 0.1, dy=torch.randn(B, T, hd, device="cuda")))
+
+    def run(p, used):
+        y, hT, gates, hn = gru_mod.gru_forward(p["gi"], p["w"], p["b"], None, save=True, scratch_out=used)
+        return (y, hT) + tuple(gru_mod.gru_backward(p["dy"], None, p["w"], None, y, gates, hn, scratch_out=used))
+
+    base = [run(p, []) for p in probs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    used, got = [], [None, None]
+    for rep in range(3):                                         # interleaved issue: fwd/bwd of both problems in flight together
+        for i, st in enumerate(streams):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                got[i] = run(probs[i], used)
+    torch.cuda.synchronize()
+    assert all(gru_mod.gru_status(s) == 0 for s in used)
+    for b_, g_ in zip(base, got):
+        for a, c in zip(b_, g_):
+            assert torch.isfinite(c).all() and torch.equal(a, c)
+
+
+@pytest.mark.gpu
+def test_gru_timeout_is_loud_everywhere():
+    """Fault injection (ddsp_gru_set_mode(2)): workgroup 0 stops publishing half way, its peers run into the (shortened)
+    spin bound.  The status word is raised, every output of the unfinished steps is NaN -- so the weight gradients the
+    caller derives from d_gi / d_gh are non-finite instead of stale memory -- and debug mode turns it into an exception."""
+    from ddsp_pytorch_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(22)
+    B, T, n_in, hd = 8, 40, 16, 128
+    _, mine = _pair(n_in, hd, 13)
+    mine = mine.cuda()
+    x = torch.randn(B, T, n_in, device="cuda")
+    gi = torch.randn(B, T, 3 * hd, device="cuda")
+    w = mine.weight_hh_l0.detach()
+    good = gru_mod.gru_forward(gi, w, None, None, save=True)
+    assert L.ddsp_gru_set_fault_step(T // 2) == 0 and L.ddsp_gru_set_mode(2) == 0
+    try:
+        used = []
+        y, hT, gates, hn = gru_mod.gru_forward(gi, w, None, None, save=True, scratch_out=used)
+        torch.cuda.synchronize()
+        assert gru_mod.gru_status(used[0]) == 1
+        # one row per group at this shape: the fault sits in row 0's group; the other groups never notice
+        assert torch.equal(y[:, :T // 2], good[0][:, :T // 2]) and torch.equal(y[1:], good[0][1:])
+        assert torch.isnan(hT[0]).all() and torch.isnan(y[0, T // 2 + 2:]).all()
+        assert torch.isnan(gates[0, T // 2 + 2:]).all() and torch.isnan(hn[0, T // 2 + 2:]).all()
+        # backward on good forward results: the reverse sweep faults at reverse step T//2, i.e. t < T - T//2 - 2 unfinished
+        used = []
+        d_gi, d_gh, dh0 = gru_mod.gru_backward(torch.randn(B, T, hd, device="cuda"), None, w, None, *good[0:1], *good[2:4],
+                                               scratch_out=used)
+        torch.cuda.synchronize()
+        assert gru_mod.gru_status(used[0]) == 1
+        assert torch.isnan(dh0[0]).all() and torch.isnan(d_gi[0, :T - T // 2 - 2]).all() and torch.isnan(d_gh[0, :T - T // 2 - 2]).all()
+        assert torch.isfinite(d_gi[:, T - T // 2:]).all() and torch.isfinite(d_gi[1:]).all() and torch.isfinite(dh0[1:]).all()
+        # module level: the parameter gradients of a step through a failed recurrence are non-finite, never garbage
+        mine.zero_grad()
+        y_mod, _ = mine(x)
+        y_mod.square().mean().backward()
+        assert not torch.isfinite(mine.weight_hh_l0.grad).all() and not torch.isfinite(mine.weight_ih_l0.grad).all()
+        old = gru_mod.set_debug(True)
+        try:
+            with pytest.raises(_lib.DdspHipError, match="timed out"):
+                mine(x)
+        finally:
+            gru_mod.set_debug(old)
+    finally:
+        L.ddsp_gru_set_mode(0)
+    y_ok, _ = mine(x)                                              # the next launch is healthy again
+    assert torch.isfinite(y_ok).all()
+
+
+@pytest.mark.gpu
+def test_gru_stacked_layers_match_torch_cpu():
+    """decoder.py:60-65 passes num_layers=conf.decoder_gru_layers: stacked layers run the HIP recurrence layer by layer."""
+    torch.manual_seed(31)
+    ref = nn.GRU(10, 48, 3, batch_first=True)
+    mine = ddsp.GRU(10, 48, 3, batch_first=True)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine = mine.cuda()
+    x = torch.randn(4, 25, 10)
+    h0 = torch.randn(3, 4, 48)
+    xr = x.clone().requires_grad_(True)
+    y_ref, h_ref = ref(xr, h0)
+    (y_ref.square().sum() + h_ref.sum()).backward()
+    xg = x.clone().cuda().requires_grad_(True)
+    y, h = mine(xg, h0.cuda())
+    (y.square().sum() + h.sum()).backward()
+    assert float((y.detach().cpu() - y_ref.detach()).abs().max()) <= 2e-5 and float((h.detach().cpu() - h_ref.detach()).abs().max()) <= 2e-5
+    assert float((xg.grad.cpu() - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
+    for (n, p), (_, q) in zip(ref.named_parameters(), mine.named_parameters()):
+        assert float((q.grad.cpu() - p.grad).abs().max()) <= 1e-4 * float(p.grad.abs().max()) + 1e-7, n
+    with torch.no_grad():                                          # and without a passed state
+        y0, _ = ref(x)
+        y1, _ = mine(x.cuda())
+    assert float((y1.cpu() - y0).abs().max()) <= 2e-5

@@ -58,6 +58,8 @@ def test_argument_validation_without_gpu():
     assert L.ddsp_scaled_sigmoid_forward(None, None, 10, None) == -1 and L.ddsp_scaled_sigmoid_forward(None, None, 0, None) == 0
     assert L.ddsp_ln_lrelu_forward(None, None, None, None, None, None, 4, 512, 1e-5, 0.01, None) == -1
     assert L.ddsp_ln_lrelu_scratch_bytes(512) > 0
+    assert L.ddsp_ln_lrelu_backward(None, None, None, None, None, None, None, None, None, None, 0, 512, 0.01, None) == -1   # empty rows still need dgamma/dbeta
+    assert L.ddsp_gru_set_fault_step(-1) == -2 and L.ddsp_gru_set_fault_step(0) == 0
 
 
 def test_module_boundary_matches_reference_contract():

@@ -65,3 +65,18 @@ def test_shard_rows_partition():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_self_launch_relays_rank_failure():
+    """`python bench.py --gpus 2` without a launcher: the parent (which imports neither torch nor the HIP library) starts the
+    ranks under torch.distributed.run as a child process.  No GPU in this container, so every rank stops with "needs a
+    GPU": the parent must hand that failure on as a non-zero exit code (on the GPU box the same path is run for real by
+    tests/test_gpu_two_ranks.py)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs a GPU" in (r.stdout + r.stderr)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]     # no bench line from a failed run
