@@ -93,6 +93,18 @@ def lib():
     L.ddsp_ln_lrelu_forward.argtypes = [vp] * 6 + [ctypes.c_long, i32, ctypes.c_float, ctypes.c_float, vp]
     L.ddsp_ln_lrelu_backward.restype = i32
     L.ddsp_ln_lrelu_backward.argtypes = [vp] * 10 + [ctypes.c_long, i32, ctypes.c_float, vp]
+    L.ddsp_reverb_impulse.restype = i32
+    L.ddsp_reverb_impulse.argtypes = [vp] * 5 + [i32, i32, vp]
+    L.ddsp_reverb_impulse_backward.restype = i32
+    L.ddsp_reverb_impulse_backward.argtypes = [vp] * 8 + [i32, i32, vp]
+    L.ddsp_spectral_mul.restype = i32
+    L.ddsp_spectral_mul.argtypes = [vp, vp, vp, ctypes.c_long, ctypes.c_long, vp]
+    L.ddsp_spectral_mul_backward.restype = i32
+    L.ddsp_spectral_mul_backward.argtypes = [vp] * 5 + [ctypes.c_long, ctypes.c_long, vp]
+    L.ddsp_reverb_live_scratch_bytes.restype = ctypes.c_size_t
+    L.ddsp_reverb_live_scratch_bytes.argtypes = [i32, i32]
+    L.ddsp_reverb_live.restype = i32
+    L.ddsp_reverb_live.argtypes = [vp] * 9 + [i32, i32, vp]
     if L.ddsp_hip_abi_version() != ABI_VERSION:
         raise DdspHipError(f"libddsp_hip.so has ABI {L.ddsp_hip_abi_version()}, expected {ABI_VERSION}: rebuild")
     _lib = L
@@ -104,7 +116,9 @@ EXPORTS = ("ddsp_hip_abi_version", "ddsp_osc_scratch_bytes", "ddsp_osc_forward",
            "ddsp_osc_set_tiling", "ddsp_noise_set_generic", "ddsp_profile_enable", "ddsp_profile_read",
            "ddsp_gru_scratch_bytes", "ddsp_gru_max_batch", "ddsp_gru_forward", "ddsp_gru_backward", "ddsp_gru_status", "ddsp_gru_set_mode", "ddsp_gru_set_fault_step",
            "ddsp_spectral_loss_scratch_bytes", "ddsp_spectral_loss", "ddsp_scaled_sigmoid_forward", "ddsp_scaled_sigmoid_backward",
-           "ddsp_ln_lrelu_scratch_bytes", "ddsp_ln_lrelu_forward", "ddsp_ln_lrelu_backward")
+           "ddsp_ln_lrelu_scratch_bytes", "ddsp_ln_lrelu_forward", "ddsp_ln_lrelu_backward",
+           "ddsp_reverb_impulse", "ddsp_reverb_impulse_backward", "ddsp_spectral_mul", "ddsp_spectral_mul_backward",
+           "ddsp_reverb_live_scratch_bytes", "ddsp_reverb_live")
 
 KERNEL_NAMES = {1: "osc_frame_totals", 2: "osc_scan", 3: "osc_frame_synth", 4: "noise_frame"}
 

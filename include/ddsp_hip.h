@@ -154,6 +154,38 @@ int ddsp_gru_set_mode(int mode);
 int ddsp_gru_set_fault_step(int step);
 
 /*
+ * Reverb (model/ddsp/reverb.py:8-49).  noise [length], t [length] (seconds), decay / wet: one device
+ * float each (the module's parameters, read on the device: nothing is synchronised).
+ *
+ * ddsp_reverb_impulse          build_impulse (:24-29) written straight into the buffer the convolution wants: taps
+ *                              [0, min(length, n_out)) = noise * exp(-softplus(-decay) * t * 500) * sigmoid(wet) with tap 0
+ *                              forced to 1 (:28), zeros up to n_out -- i.e. `F.pad(impulse, (0, n_out - length))` of :34,
+ *                              which CROPS when n_out < length.
+ * ddsp_reverb_impulse_backward gradient of the first n_used (<= length) taps w.r.t. noise [length] (zero where cropped and
+ *                              at tap 0), decay and wet (one float each); deterministic.
+ * ddsp_spectral_mul            y[r,f] = x[r,f] * k[f] on interleaved re/im spectra ([rows, bins] x [bins]): the product of
+ *                              fft_convolve (filtered_noise.py:28-30) with one kernel shared by the rows.  The 2N-point real
+ *                              transforms themselves stay library FFTs on the caller's side.
+ * ddsp_spectral_mul_backward   gk[r,f] = g[r,f] conj(k[f]) (-> irfft -> grad of the signal; nullable) and
+ *                              s[f] = sum_r g[r,f] conj(x[r,f]) (-> irfft -> grad of the kernel; nullable, rows summed in order).
+ * ddsp_reverb_live             live_forward (:40-49): history_out = [history_in[n:], x]; y[j] = the last n samples of the
+ *                              causal convolution of that window with the impulse, computed directly (n x length
+ *                              multiply-adds, no FFT).  x [n], y [n], history_* [length], history_out must not alias
+ *                              history_in; scratch >= ddsp_reverb_live_scratch_bytes(length, n); n <= length.
+ */
+int ddsp_reverb_impulse(const float *noise, const float *decay, const float *wet, const float *t, float *impulse,
+                        int length, int n_out, void *stream);
+int ddsp_reverb_impulse_backward(const float *grad_impulse, const float *noise, const float *decay, const float *wet,
+                                 const float *t, float *grad_noise, float *grad_decay, float *grad_wet, int length,
+                                 int n_used, void *stream);
+int ddsp_spectral_mul(const float *x_ri, const float *k_ri, float *y_ri, long rows, long bins, void *stream);
+int ddsp_spectral_mul_backward(const float *g_ri, const float *x_ri, const float *k_ri, float *gk_ri, float *s_ri,
+                               long rows, long bins, void *stream);
+size_t ddsp_reverb_live_scratch_bytes(int length, int n);
+int ddsp_reverb_live(const float *x, const float *history_in, float *history_out, const float *noise, const float *decay,
+                     const float *wet, const float *t, float *y, void *scratch, int length, int n, void *stream);
+
+/*
  * One scale of the multi-scale spectral loss (loss/mss_loss.py:11-33: L1 of the power spectrograms + alpha * L1 of their
  * log2) fused into one pass over the two complex STFTs (interleaved re/im, n_bins complex bins each), with the
  * gradient w.r.t. the predicted STFT produced in the same pass (grad_ri nullable).  out3 (device) = {loss, linear term,

@@ -214,7 +214,7 @@ def test_cfg5_per_gpu_train_step_full_shape():
             p.grad = None
         loss = loss_fn(model({k: v[sl] for k, v in batch.items()}), batch["audio"][sl])
         loss.backward()
-        return float(loss), [p.grad.detach().clone() for p in params]
+        return float(loss.detach()), [p.grad.detach().clone() for p in params]
 
     old = gru_mod.set_debug(True)
     try:
