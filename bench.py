@@ -66,6 +66,32 @@ class Conf:
         self.n_harmonics, self.sample_rate, self.hop_length = shape.n_harmonics, shape.sample_rate, shape.hop
 
 
+def kernel_sources_stamp():
+    """sha256 over the HIP sources the library is built from: ties a PMC file to the kernels it measured."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "ddsp-pytorch_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "ddsp-pytorch_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc():
+    """Newest profiles/rNN_pmc.json whose stamp matches the current kernel sources -> (dict, file name) or (None, None)."""
+    import glob
+    stamp = kernel_sources_stamp()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:  # noqa: BLE001
+            continue
+        if d.get("_meta", {}).get("kernel_sources_sha") == stamp:
+            return d, os.path.basename(f)
+    return None, None
+
+
 def cpu_baseline(shape, seconds_target=12.0):
     """Reference CPU path (torch-op restatement) on a bounded sample: B=8 rows of the same workload."""
     from oracle import torch_restatement as tr
@@ -114,13 +140,15 @@ def train_mode(args, rank, world, dist):
             dist.barrier()
             torch.cuda.synchronize()
 
+    amp_dtype = {"none": None, "bf16": torch.bfloat16, "fp16": torch.float16}[args.amp]
+    scaler = torch.amp.GradScaler("cuda") if args.amp == "fp16" else None
     nbytes = 0
     for _ in range(args.warmup):
-        _, nbytes = ddsp.train_step(model, loss_fn, opt, batch)
+        _, nbytes = ddsp.train_step(model, loss_fn, opt, batch, amp_dtype=amp_dtype, scaler=scaler)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, nbytes = ddsp.train_step(model, loss_fn, opt, batch)
+        loss, nbytes = ddsp.train_step(model, loss_fn, opt, batch, amp_dtype=amp_dtype, scaler=scaler)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -132,7 +160,8 @@ def train_mode(args, rank, world, dist):
             "metric": "train-step audio samples/sec (BASELINE.json configs[4]; secondary figure)",
             "value": world * b * frames * 128 * args.steps / elapsed, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.amp == "none" else f"{args.amp} GEMMs (autocast), f32 synthesis / loss / optimiser", "data": "synthetic",
             "config": {"workload": f"decoder (4.84 M params) + HIP synth + reverb + MSS loss (6 scales) + Adam, batch {b}/GPU, "
                                    f"16 kHz, 100 harmonics, 65 noise bands, 4 s", "parallelism": f"dp{world}, one flat all-reduce",
                        "allreduce_bytes": nbytes},
@@ -155,6 +184,9 @@ def main():
     ap.add_argument("--mode", default="synth", choices=["synth", "train"],
                     help="synth: the headline hot path; train: BASELINE.json configs[4] (decoder + MSS loss + Adam, "
                          "batch 32/GPU, flat RCCL gradient all-reduce) -- a secondary figure, not the metric")
+    ap.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"],
+                    help="train mode: autocast dtype of the dense layers' GEMMs (reference: precision=16, train/train.py:50); "
+                         "off by default, the synthesis kernels stay fp32 either way")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--one-device", action="store_true",
@@ -235,16 +267,25 @@ def main():
         launch_samples = shape.batch * shape.samples
         achieved = launch_samples * bytes_per_sample / (synth_ms * 1e-3) / 1e9
         hs_per_s = launch_samples * shape.n_harmonics / (synth_ms * 1e-3)
-        traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc.json")
-        if os.path.exists(pmc_file) and not args.batch and not args.tiling and not args.harmonics:
-            # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (not measurable live)
-            try:
-                k = [v for n, v in json.load(open(pmc_file)).items() if n.startswith("osc_synth_kernel") and "hbm_bytes_per_launch" in v]
-                if k:
-                    traffic, traffic_src = max(x["hbm_bytes_per_launch"] for x in k), "profiles/r01_pmc.json (FETCH_SIZE x2 + WRITE_SIZE)"
-            except Exception:  # noqa: BLE001
-                pass
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (not measurable live); used
+        # only when the file was measured on exactly the kernel sources this run was built from (stamp written by
+        # tools/summarise_profiles.py), otherwise traffic is null rather than stale
+        pmc, pmc_name = load_pmc() if not (args.batch or args.tiling or args.harmonics) else (None, None)
+
+        def traffic_of(prefix):
+            if not pmc:
+                return None
+            k = [v for n, v in pmc.items() if n.startswith(prefix) and isinstance(v, dict) and "hbm_bytes_per_launch" in v]
+            return max(x["hbm_bytes_per_launch"] for x in k) if k else None
+
+        traffic = traffic_of("osc_synth_kernel")
+        traffic_src = f"profiles/{pmc_name} (FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None
+        # the kernel SURVEY §8(d) says can approach the HBM roof: 4 (y) + 4 F / hop (H) bytes per sample (the draw is made
+        # in the kernel; the accumulate's read of y is the oscillator's output coming back, not counted as algorithmic)
+        noise_ms = kern_ms.get("noise_frame", float("nan"))
+        noise_bps = 4.0 + 4.0 * shape.n_noise_filters / shape.hop
+        noise_achieved = launch_samples * noise_bps / (noise_ms * 1e-3) / 1e9
+        noise_macs = shape.hop / 2.0 + shape.n_noise_filters          # direct form: truncated convolution + inverse DFT, per sample
         line = {
             "metric": "audio samples/sec/GPU + %HBM-roofline, 16kHz/100-harmonic/batch512",
             "value": samples_per_step * args.steps / elapsed,
@@ -267,7 +308,16 @@ def main():
                          "note": "kernel is VALU-bound (SURVEY §8d): see valu",
                          "valu": {"harmonic_samples_per_s": hs_per_s, "lane_ops_per_harmonic_sample": 12,
                                   "achieved_Tlaneops": hs_per_s * 12 / 1e12, "peak_Tlaneops": VALU_PEAK_TLANEOPS,
-                                  "frac": hs_per_s * 12 / 1e12 / VALU_PEAK_TLANEOPS}},
+                                  "frac": hs_per_s * 12 / 1e12 / VALU_PEAK_TLANEOPS},
+                         "noise_frame": {"bound": "hbm", "kernel": "noise_frame", "achieved": noise_achieved, "peak": HBM_PEAK_GBS,
+                                         "unit": "GB/s", "frac": noise_achieved / HBM_PEAK_GBS, "traffic": traffic_of("noise_batched_kernel"),
+                                         "algorithmic_bytes_per_launch": launch_samples * noise_bps,
+                                         "algorithmic_bytes_per_sample": noise_bps, "avg_launch_ms": noise_ms,
+                                         "note": "direct form at hop 128: (hop/2 + F) multiply-adds per sample -> VALU-bound too",
+                                         "valu": {"mac_per_sample": noise_macs,
+                                                  "achieved_Tlaneops": launch_samples * noise_macs / (noise_ms * 1e-3) / 1e12,
+                                                  "peak_Tlaneops": VALU_PEAK_TLANEOPS,
+                                                  "frac": launch_samples * noise_macs / (noise_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS}}},
             "kernel_ms": kern_ms,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -34,6 +34,7 @@ class _LayerNormLeakyReLU(torch.autograd.Function):
     """LayerNorm -> LeakyReLU of one MLP block as one HIP pass each way (include/ddsp_hip.h: ddsp_ln_lrelu_*)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, gamma, beta, eps, slope):
         x = x.contiguous()
         D = x.shape[-1]
@@ -51,6 +52,7 @@ class _LayerNormLeakyReLU(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gy):
         x, y, g, mean, rstd = ctx.saved_tensors
         D = x.shape[-1]
@@ -67,12 +69,17 @@ class _LayerNormLeakyReLU(torch.autograd.Function):
         return gx, dg, db, None, None
 
 
+# Under torch.autocast the Linear layers hand over bf16 / fp16 activations; the fused passes take them (their
+# `custom_fwd(cast_inputs=float32)` converts) and return fp32, so only the GEMMs run in the low-precision type.
+_FUSED_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
+
+
 def _run_stack(stack: nn.Module, x: torch.Tensor) -> torch.Tensor:
     for i in range(stack.depth):
         linear, norm, act = getattr(stack, f"mlp_layer{i + 1}")
         x = linear(x)
         D = x.shape[-1]
-        if (x.is_cuda and x.dtype == torch.float32 and D % 256 == 0 and D <= 1024 and norm.elementwise_affine
+        if (x.is_cuda and x.dtype in _FUSED_DTYPES and D % 256 == 0 and D <= 1024 and norm.elementwise_affine
                 and norm.bias is not None and act.negative_slope > 0):
             x = _LayerNormLeakyReLU.apply(x, norm.weight, norm.bias, norm.eps, act.negative_slope)
         else:
@@ -84,6 +91,7 @@ class _ScaledSigmoid(torch.autograd.Function):
     """One HIP pass forward, one backward (include/ddsp_hip.h: ddsp_scaled_sigmoid_*)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x):
         x = x.contiguous()
         y = torch.empty_like(x)
@@ -94,6 +102,7 @@ class _ScaledSigmoid(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
         gy = gy.contiguous()
@@ -106,7 +115,7 @@ class _ScaledSigmoid(torch.autograd.Function):
 
 def scaled_sigmoid(x: torch.Tensor) -> torch.Tensor:
     """decoder.py:110-116: 2*sigmoid(x)^ln(10) + 1e-7 (the value range of every synth control)."""
-    if x.is_cuda and x.dtype == torch.float32:
+    if x.is_cuda and x.dtype in _FUSED_DTYPES:
         return _ScaledSigmoid.apply(x)
     return 2.0 * torch.sigmoid(x).pow(2.3026) + 1e-7
 

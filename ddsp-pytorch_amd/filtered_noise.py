@@ -68,6 +68,7 @@ class _NoiseFunction(torch.autograd.Function):
     """Differentiable w.r.t. H; the noise draw is a constant of the graph (filtered_noise.py:44-48)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, Hmag, uniform, hop, seed, offset):
         if uniform is not None:
             uniform = uniform.detach().to(device=Hmag.device, dtype=torch.float32).contiguous()
@@ -77,6 +78,7 @@ class _NoiseFunction(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_y):
         (uniform,) = ctx.saved_tensors
         hop, nf, seed, offset = ctx.meta

@@ -111,7 +111,8 @@ def gru_status(scratch) -> int:
 
 class _Recurrence(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, gi, w_hh, b_hh, h0):
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, gi, w_hh, b_hh, h0, gemm_dtype=None):
         gi = gi.contiguous().float()
         w = w_hh.detach().contiguous().float()
         b = None if b_hh is None else b_hh.detach().contiguous().float()
@@ -124,9 +125,11 @@ class _Recurrence(torch.autograd.Function):
         if need:
             ctx.save_for_backward(w, h, y, gates, hn)
             ctx.has_bias = b is not None
+            ctx.gemm_dtype = gemm_dtype
         return y, hT
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy, dhT):
         w, h0, y, gates, hn = ctx.saved_tensors
         B, T, Hd = y.shape
@@ -140,10 +143,14 @@ class _Recurrence(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             first = h0 if h0 is not None else torch.zeros((B, Hd), device=y.device, dtype=y.dtype)
             h_prev = torch.cat((first.unsqueeze(1), y[:, :-1]), dim=1)          # h_{t-1} for every step
-            dw = d_gh.reshape(B * T, 3 * Hd).t() @ h_prev.reshape(B * T, Hd)  # library GEMM [3Hd, BT] x [BT, Hd]
+            a, b_ = d_gh.reshape(B * T, 3 * Hd), h_prev.reshape(B * T, Hd)
+            if ctx.gemm_dtype is not None:                                      # the forward ran under autocast: so does this GEMM
+                dw = (a.to(ctx.gemm_dtype).t() @ b_.to(ctx.gemm_dtype)).float()
+            else:
+                dw = a.t() @ b_                                                 # library GEMM [3Hd, BT] x [BT, Hd]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = d_gh.sum(dim=(0, 1))
-        return d_gi, dw, db, (dh0 if ctx.needs_input_grad[3] else None)
+        return d_gi, dw, db, (dh0 if ctx.needs_input_grad[3] else None), None
 
 
 class GRU(nn.GRU):
@@ -152,7 +159,7 @@ class GRU(nn.GRU):
     def _hip_eligible(self, x) -> bool:
         # anything that is not a dense batched CUDA tensor (PackedSequence, unbatched 2-D input, CPU) is nn.GRU's business
         return (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 3 and not self.bidirectional and self.proj_size == 0
-                and self.hidden_size <= 512 and x.dtype == torch.float32)
+                and self.hidden_size <= 512 and x.dtype in (torch.float32, torch.bfloat16, torch.float16))
 
     def forward(self, input, hx=None):  # noqa: A002 (torch's argument name)
         if not self._hip_eligible(input):
@@ -162,11 +169,12 @@ class GRU(nn.GRU):
                                or hx.shape[2] != self.hidden_size):
             raise RuntimeError(f"Expected hidden size ({self.num_layers}, {x.shape[0]}, {self.hidden_size}), got {list(hx.shape)}")
         finals = []
+        amp = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
         for layer in range(self.num_layers):     # decoder.py:60-65 `num_layers=conf.decoder_gru_layers`: stacked, layer by layer
             b_ih = getattr(self, f"bias_ih_l{layer}", None) if self.bias else None
             b_hh = getattr(self, f"bias_hh_l{layer}", None) if self.bias else None
             gi = F.linear(x, getattr(self, f"weight_ih_l{layer}"), b_ih)
-            x, hT = _Recurrence.apply(gi, getattr(self, f"weight_hh_l{layer}"), b_hh, None if hx is None else hx[layer])
+            x, hT = _Recurrence.apply(gi, getattr(self, f"weight_hh_l{layer}"), b_hh, None if hx is None else hx[layer], amp)
             finals.append(hT)
             if self.dropout > 0 and self.training and layer + 1 < self.num_layers:
                 x = F.dropout(x, self.dropout, True)

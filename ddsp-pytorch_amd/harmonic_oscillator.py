@@ -73,6 +73,7 @@ class _OscillatorFunction(torch.autograd.Function):
     """Differentiable w.r.t. c and a (train/train.py:33-34); f0 carries no gradient (decoder.py:105)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, f0, c, a, hop, sample_rate):
         f0 = f0.detach().contiguous().float()
         c = c.detach().contiguous().float()
@@ -83,6 +84,7 @@ class _OscillatorFunction(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_y):
         f0, c, a, scratch = ctx.saved_tensors
         grad_c, grad_a = osc_backward(grad_y, f0, c, a, scratch, ctx.hop, ctx.sample_rate)

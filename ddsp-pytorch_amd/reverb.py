@@ -52,6 +52,7 @@ class _ReverbFunction(torch.autograd.Function):
     """y = first N samples of x * impulse(noise, decay, wet); differentiable w.r.t. x, noise, decay, wet."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, noise, decay, wet, t):
         L = _lib.lib()
         x = x.detach().contiguous().float()
@@ -73,6 +74,7 @@ class _ReverbFunction(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_y):
         x_spec, k_spec, noise, decay, wet, t = ctx.saved_tensors
         L = _lib.lib()

@@ -25,6 +25,7 @@ class _FusedSpectralL1(torch.autograd.Function):
     d loss / d pred for the backward."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, pred_ri, true_ri, alpha, eps):
         L = _lib.lib()
         need = ctx.needs_input_grad[0]
@@ -41,6 +42,7 @@ class _FusedSpectralL1(torch.autograd.Function):
         return out[0]
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
         return grad * g, None, None, None
@@ -123,9 +125,16 @@ def allreduce_gradients(params, group=None) -> int:
     return nbytes
 
 
-def train_step(model: nn.Module, loss_fn: nn.Module, optimizer: torch.optim.Optimizer, batch, group=None):
+def train_step(model: nn.Module, loss_fn: nn.Module, optimizer: torch.optim.Optimizer, batch, group=None, amp_dtype=None,
+               scaler=None):
     """One optimisation step of `Zak.training_step` (train/train.py:32-37) + Adam, data-parallel.
-    `batch` is this rank's shard: a dict with the controller inputs and the target `audio`."""
+    `batch` is this rank's shard: a dict with the controller inputs and the target `audio`.
+    `amp_dtype` (torch.bfloat16 / torch.float16; default None = fp32 everywhere): the reference trains with
+    `precision=16` (train/train.py:50, Lightning's native AMP).  Here it is `torch.autocast` around the model: the dense
+    layers' GEMMs (controller MLPs, GRU input projection and weight gradient, heads) run in that type on the matrix
+    cores with fp32 accumulation, while every HIP kernel of this package -- synthesis, recurrence, fused normalisation,
+    spectral loss -- and the parameters, gradients and optimiser state stay fp32.  `scaler`: an optional
+    `torch.amp.GradScaler` (what Lightning adds for fp16; bf16 needs none)."""
     optimizer.zero_grad(set_to_none=True)
     rows = next((v.shape[0] for v in batch.values() if torch.is_tensor(v)), 0) if isinstance(batch, dict) else len(batch)
     if rows == 0:
@@ -136,9 +145,14 @@ def train_step(model: nn.Module, loss_fn: nn.Module, optimizer: torch.optim.Opti
             p.grad = torch.zeros_like(p)
         loss = torch.zeros((), device=params[0].device if params else "cpu")
     else:
-        audio = model(batch)
-        loss = loss_fn(audio, batch)
-        loss.backward()
+        with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
+            audio = model(batch)
+        loss = loss_fn(audio.float(), batch)
+        (scaler.scale(loss) if scaler is not None else loss).backward()
     nbytes = allreduce_gradients([p for p in model.parameters() if p.requires_grad], group)
-    optimizer.step()
+    if scaler is not None:
+        scaler.step(optimizer)     # unscales, skips the step on inf / nan (the averaged gradients are still scaled here)
+        scaler.update()
+    else:
+        optimizer.step()
     return loss.detach(), nbytes

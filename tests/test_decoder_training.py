@@ -366,3 +366,43 @@ def test_decoder_gradients_match_reference_autograd_fixture():
         ref = g["g__" + n]
         err = float(np.max(np.abs(got[n].grad.cpu().numpy() - ref)))
         assert err <= 2e-4 * max(1.0, float(np.max(np.abs(ref)))), (n, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("amp_dtype", [torch.bfloat16, torch.float16])
+def test_train_step_autocast_gemms_track_fp32(amp_dtype):
+    """`train_step(..., amp_dtype=...)` (the reference's precision=16, train/train.py:50): only the dense layers' GEMMs run in the
+    low-precision type; synthesis, recurrence, fused passes, loss and the optimiser stay fp32.  The loss and every gradient
+    must track the fp32 step at that type's tolerance (cosine >= 0.99 for the big tensors), parameters stay fp32."""
+    class Conf:
+        n_harmonics, n_noise_filters, sample_rate, hop_length = 100, 65, 16000, 128
+        decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 256, 2, 128, 1
+
+    rng = np.random.default_rng(4)
+    B, T = 4, 40
+    batch = {"normalized_cents": torch.from_numpy(rng.uniform(0, 1, (B, T, 1)).astype(np.float32)).cuda(),
+             "loudness": torch.from_numpy(rng.uniform(-1, 1, (B, T, 1)).astype(np.float32)).cuda(),
+             "f0": torch.from_numpy(rng.uniform(80, 400, (B, T, 1)).astype(np.float32)).cuda(),
+             "audio": torch.from_numpy((0.1 * rng.standard_normal((B, T * 128))).astype(np.float32)).cuda()}
+    loss_fn = ddsp.MSSLoss().cuda()
+
+    def one(amp):
+        torch.manual_seed(9)
+        model = ddsp.Decoder(Conf, noise_rng="device", seed=3).cuda()
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)          # lr 0: keep the gradients, leave the weights
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0) if amp == torch.float16 else None
+        loss, _ = ddsp.train_step(model, loss_fn, opt, batch, amp_dtype=amp, scaler=scaler)
+        scale = scaler.get_scale() if scaler is not None else 1.0
+        assert all(p.dtype == torch.float32 and p.grad.dtype == torch.float32 for p in model.parameters() if p.requires_grad)
+        return float(loss), {n: p.grad.detach().clone() / (1024.0 if scaler is not None else 1.0)
+                             for n, p in model.named_parameters() if p.requires_grad}, scale
+
+    l32, g32, _ = one(None)
+    l16, g16, _ = one(amp_dtype)
+    assert np.isfinite(l16) and abs(l16 - l32) <= 2e-2 * abs(l32)
+    for n, g in g32.items():
+        h = g16[n]
+        assert torch.isfinite(h).all(), n
+        if g.numel() >= 64 and float(g.norm()) > 0:
+            cos = float((g * h).sum() / (g.norm() * h.norm() + 1e-30))
+            assert cos >= 0.99, (n, cos)

@@ -56,6 +56,15 @@ for k, cs in pmc.items():
     if d.get("GRBM_GUI_ACTIVE") and d.get("SQ_INSTS_VALU"):
         d["cycles_per_valu_inst_per_simd"] = (d["GRBM_GUI_ACTIVE"] / 8.0) / (d["SQ_INSTS_VALU"] / 1024.0)
     out[k] = d
+# stamp: the kernel sources these counters were measured on (bench.py drops `roofline.traffic` when HEAD's sources differ)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import subprocess
+    import bench
+    head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    out["_meta"] = {"kernel_sources_sha": bench.kernel_sources_stamp(), "round": rnd, "git_head": head or None}
+except Exception as e:  # noqa: BLE001
+    out["_meta"] = {"error": str(e)}
 json.dump(out, open(os.path.join(dst, f"{rnd}_pmc.json"), "w"), indent=1, sort_keys=True)
 try:
     line = open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1]
@@ -66,4 +75,4 @@ except Exception as e:  # noqa: BLE001
 for r in rows:
     print(r)
 for k, d in out.items():
-    print(k, {c: f"{v:.4g}" for c, v in d.items()})
+    print(k, {c: (f"{v:.4g}" if isinstance(v, float) else v) for c, v in d.items()})
