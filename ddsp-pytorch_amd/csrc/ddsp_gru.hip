@@ -26,6 +26,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "ddsp_hip.h"
@@ -484,8 +485,8 @@ __global__ void __launch_bounds__(256 * NRS, 1) gru_bwd_kernel(GruParams p)
 
 // ---- host side ----------------------------------------------------------------------------------------------
 struct GruPlan { int KP, HP, NW, NG, NGpad, BL; };
-int g_gru_mode = 0;        // ddsp_gru_set_mode: bit 0 = spread placement, bit 1 = fault injection (tests)
-int g_gru_fault_step = 0;  // with bit 1: workgroup 0 withholds its publishes from this step on
+std::atomic<int> g_gru_mode{0};        // ddsp_gru_set_mode: bit 0 = spread placement, bit 1 = fault injection (tests)
+std::atomic<int> g_gru_fault_step{0};  // with bit 1: workgroup 0 withholds its publishes from this step on
 
 // Co-residency guard, part 2: two persistent launches that each want one workgroup per CU must not run at the same time
 // on one device (two streams of a process could each get part of the CUs and starve each other into the timeout).  Every
@@ -607,12 +608,13 @@ int run_gru(GruParams &p, void *scratch, bool backward, hipStream_t s)
     const int rc = device_cus(&cus);
     if (rc) return rc;
     GruPlan pl;
-    if (!plan_gru(p.B, p.Hd, cus, backward ? kMaxRowsBwd : kMaxRows, (g_gru_mode & 1) != 0, &pl)) return DDSP_ERANGE;
+    const int mode = g_gru_mode.load(std::memory_order_relaxed);   // test hooks: one snapshot per launch
+    if (!plan_gru(p.B, p.Hd, cus, backward ? kMaxRowsBwd : kMaxRows, (mode & 1) != 0, &pl)) return DDSP_ERANGE;
     p.NG = pl.NG; p.NGpad = pl.NGpad; p.NW = pl.NW; p.BL = pl.BL;
     const int payloads = backward ? 3 : 1;
-    const bool inject = (g_gru_mode & 2) != 0;
+    const bool inject = (mode & 2) != 0;
     p.spin_ticks = inject ? kSpinTicksFaultTest : kSpinTicks;
-    p.fault_step = inject ? g_gru_fault_step : -1;
+    p.fault_step = inject ? g_gru_fault_step.load(std::memory_order_relaxed) : -1;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
@@ -704,14 +706,14 @@ extern "C" int ddsp_gru_backward(const float *dy, const float *dhT, const float 
 extern "C" int ddsp_gru_set_mode(int mode)
 {
     if (mode < 0 || mode > 3) return DDSP_ERANGE;
-    g_gru_mode = mode;
+    g_gru_mode.store(mode, std::memory_order_relaxed);
     return 0;
 }
 
 extern "C" int ddsp_gru_set_fault_step(int step)
 {
     if (step < 0) return DDSP_ERANGE;
-    g_gru_fault_step = step;
+    g_gru_fault_step.store(step, std::memory_order_relaxed);
     return 0;
 }
 

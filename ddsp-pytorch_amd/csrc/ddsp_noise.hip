@@ -15,12 +15,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "ddsp_hip.h"
 #include "ddsp_internal.h"
 
 namespace {
 
-int g_force_generic = 0;  // ddsp_noise_set_generic: tests exercise the one-frame-per-workgroup kernel
+std::atomic<int> g_force_generic{0};  // ddsp_noise_set_generic: tests exercise the one-frame-per-workgroup kernel (read once per launch)
 
 struct NoiseParams {
     const float *Hm;
@@ -526,9 +528,9 @@ size_t batched_lds_bytes(int F, int R, int lpf_log)
 
 // Lanes per frame (log2) of the batched forward kernel: 64 frames per workgroup when the tile fits in ~half the
 // CU's LDS (two workgroups per CU), else 32 / 16 frames; -1 when even 16 frames do not fit (generic kernel then).
-int pick_lpf_log(int F, int R)
+int pick_lpf_log(int F, int R, int mode)
 {
-    if (g_force_generic >> 8) return (g_force_generic >> 8) - 1;  // tuning: ddsp_noise_set_generic((l + 1) << 8)
+    if (mode >> 8) return (mode >> 8) - 1;  // tuning: ddsp_noise_set_generic((l + 1) << 8)
     // measured (hop 128, F 65): 32 frames / 35 KB per workgroup (4 workgroups per CU) beats 64 frames / 70 KB by 14 %
     for (int l = 0; l <= 3; ++l)
         if (batched_lds_bytes(F, R, l) <= 40 * 1024) return l;
@@ -571,8 +573,10 @@ int noise_forward_impl(const float *Hmag, const float *uniform, float *y, int B,
     p.seed = seed; p.offset = offset; p.offset_dev = offset_dev; p.accumulate = accumulate; p.lpf_log = 0;
     if ((long)B * T >= (1L << 31)) return DDSP_ERANGE;
     hipStream_t s = (hipStream_t)stream;
-    const int lpf_log = pick_lpf_log(F, hop);
-    if (!(g_force_generic & 1) && hop % 8 == 0 && lpf_log >= 0 && ((uintptr_t)y % 16) == 0) {
+    const int mode = g_force_generic.load(std::memory_order_relaxed);
+    const int lpf_log = pick_lpf_log(F, hop, mode);
+    // (the batched kernel stores whole float4s: an output buffer that is not 16-byte aligned takes the generic kernel)
+    if (!(mode & 1) && hop % 8 == 0 && lpf_log >= 0 && ((uintptr_t)y % 16) == 0) {
         const size_t blds = batched_lds_bytes(F, hop, lpf_log);
         p.lpf_log = lpf_log;
         static bool attr_set[64] = {};
@@ -586,7 +590,12 @@ int noise_forward_impl(const float *Hmag, const float *uniform, float *y, int B,
         return (int)hipGetLastError();
     }
     const size_t lds = sizeof(float) * ((size_t)F + p.S + 2 * (size_t)hop);
-    if (lds > 64 * 1024) return DDSP_ERANGE;
+    if (lds > 160 * 1024) return DDSP_ERANGE;
+    {
+        static bool attr_set[64] = {};
+        const hipError_t ae = ddsp_allow_big_lds((const void *)noise_frame_kernel, attr_set);
+        if (ae != hipSuccess) return (int)ae;
+    }
     const int slot = ddsp_prof::begin(ddsp_prof::NOISE, s);
     hipLaunchKernelGGL(noise_frame_kernel, dim3((unsigned)((long)B * T)), dim3(256), lds, s, p);
     ddsp_prof::end(slot, s);
@@ -596,7 +605,7 @@ int noise_forward_impl(const float *Hmag, const float *uniform, float *y, int B,
 
 extern "C" int ddsp_noise_set_generic(int on)
 {
-    g_force_generic = on;
+    g_force_generic.store(on, std::memory_order_relaxed);
     return 0;
 }
 
@@ -613,7 +622,7 @@ extern "C" int ddsp_noise_backward(const float *grad_y, const float *uniform, fl
     hipStream_t s = (hipStream_t)stream;
     const int lpf_log = pick_bwd_lpf_log(F, hop);
     p.lpf_log = lpf_log < 0 ? 0 : lpf_log;
-    if (!(g_force_generic & 1) && hop % 8 == 0 && lpf_log >= 0) {
+    if (!(g_force_generic.load(std::memory_order_relaxed) & 1) && hop % 8 == 0 && lpf_log >= 0) {
         const size_t blds = bwd_batched_lds_bytes(F, hop, lpf_log);
         static bool attr_set[64] = {};
         const hipError_t ae = ddsp_allow_big_lds((const void *)noise_bwd_batched_kernel, attr_set);
@@ -624,7 +633,12 @@ extern "C" int ddsp_noise_backward(const float *grad_y, const float *uniform, fl
         return (int)hipGetLastError();
     }
     const size_t lds = sizeof(float) * ((size_t)p.S + 2 * (size_t)hop + p.S / 2 + 1);
-    if (lds > 64 * 1024) return DDSP_ERANGE;
+    if (lds > 160 * 1024) return DDSP_ERANGE;
+    {
+        static bool attr_set[64] = {};
+        const hipError_t ae = ddsp_allow_big_lds((const void *)noise_bwd_frame_kernel, attr_set);
+        if (ae != hipSuccess) return (int)ae;
+    }
     hipLaunchKernelGGL(noise_bwd_frame_kernel, dim3((unsigned)((long)B * T)), dim3(256), lds, s, p);
     return (int)hipGetLastError();
 }

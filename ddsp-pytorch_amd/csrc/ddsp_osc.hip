@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "ddsp_hip.h"
 #include "ddsp_internal.h"
 #include "ddsp_osc_common.h"
@@ -535,14 +537,15 @@ double tiling_cost(int H, int K, int logG, long frames)
     return waste * shared * occupancy / fill;
 }
 
-int g_forced_k = 0;  // ddsp_osc_set_tiling: 0 = automatic
+std::atomic<int> g_forced_k{0};  // ddsp_osc_set_tiling: 0 = automatic (a test / tuning hook; read once per launch)
 
 bool pick_tiling(int H, long frames, Tiling *out)
 {
     double best = 1e30;
     bool found = false;
+    const int forced = g_forced_k.load(std::memory_order_relaxed);
     for (int K : kKs) {
-        if (g_forced_k && K != g_forced_k) continue;
+        if (forced && K != forced) continue;
         const int lanes = (H + K - 1) / K;
         int logG = 0;
         while ((1 << logG) < lanes) ++logG;
@@ -590,7 +593,7 @@ extern "C" int ddsp_osc_set_tiling(int harmonics_per_lane)
         for (int K : kKs) known = known || (K == harmonics_per_lane);
         if (!known) return DDSP_ERANGE;
     }
-    g_forced_k = harmonics_per_lane;
+    g_forced_k.store(harmonics_per_lane, std::memory_order_relaxed);
     return 0;
 }
 

@@ -314,7 +314,7 @@ def test_shape_limits_are_reported_not_computed():
     assert empty.shape == (0, 24)
 
 
-@pytest.mark.parametrize("nf,hop", [(2, 8), (3, 8), (2, 5), (9, 16), (130, 8)])
+@pytest.mark.parametrize("nf,hop", [(2, 8), (3, 8), (2, 5), (9, 16), (130, 8), (129, 8192)])   # last: generic kernel, > 64 KiB of LDS
 def test_noise_edge_shapes_vs_oracle(nf, hop):
     rng = np.random.default_rng(nf * 100 + hop)
     H = syn.controller_range(rng.standard_normal((2, 5, nf), dtype=np.float32))
