@@ -19,40 +19,13 @@
 
 #include "ddsp_hip.h"
 #include "ddsp_internal.h"
+#include "ddsp_noise_common.h"
+
+using namespace ddsp_noise;
 
 namespace {
 
 std::atomic<int> g_force_generic{0};  // ddsp_noise_set_generic: tests exercise the one-frame-per-workgroup kernel (read once per launch)
-
-struct NoiseParams {
-    const float *Hm;
-    const float *u;
-    float *y;
-    int B, T, F, R, S;
-    uint64_t seed, offset;
-    const uint64_t *offset_dev;  // nullable: the draw starts at offset + *offset_dev (a device counter: hipGraph replays)
-    int accumulate;
-    int lpf_log; // batched kernel: log2(lanes per frame) -> 64 >> lpf_log frames per workgroup
-};
-
-// Philox4x32-10 (Salmon et al. 2011), counter = (c0,c1,0,0), key = seed.
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t (&out)[4])
-{
-    uint32_t c[4] = {c0, c1, 0u, 0u};
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-        const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-        const uint32_t n3 = (uint32_t)p0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
-}
 
 __global__ void __launch_bounds__(256) noise_frame_kernel(NoiseParams p)
 {
@@ -574,6 +547,11 @@ int noise_forward_impl(const float *Hmag, const float *uniform, float *y, int B,
     if ((long)B * T >= (1L << 31)) return DDSP_ERANGE;
     hipStream_t s = (hipStream_t)stream;
     const int mode = g_force_generic.load(std::memory_order_relaxed);
+    // power-of-two hops 256 / 512: the in-LDS FFT form (ddsp_noise_fft.hip); mode bit 1 (tests, A/B) keeps the direct forms
+    if (!(mode & 3)) {
+        hipError_t fe = hipSuccess;
+        if (launch_noise_fft(p, s, &fe)) return (int)fe;
+    }
     const int lpf_log = pick_lpf_log(F, hop, mode);
     // (the batched kernel stores whole float4s: an output buffer that is not 16-byte aligned takes the generic kernel)
     if (!(mode & 1) && hop % 8 == 0 && lpf_log >= 0 && ((uintptr_t)y % 16) == 0) {

@@ -1,0 +1,46 @@
+// Shared by the filtered-noise kernels (ddsp_noise.hip: direct forms, ddsp_noise_fft.hip: in-LDS FFT form).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ddsp_noise {
+
+struct NoiseParams {
+    const float *Hm;
+    const float *u;
+    float *y;
+    int B, T, F, R, S;
+    uint64_t seed, offset;
+    const uint64_t *offset_dev;  // nullable: the draw starts at offset + *offset_dev (a device counter: hipGraph replays)
+    int accumulate;
+    int lpf_log; // batched kernel: log2(lanes per frame) -> 64 >> lpf_log frames per workgroup
+};
+
+// Philox4x32-10 (Salmon et al. 2011), counter = (c0,c1,0,0), key = seed.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t (&out)[4])
+{
+    uint32_t c[4] = {c0, c1, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+
+// One U[0,1) draw of the in-kernel stream as x = 2u - 1 (same expression order in every kernel: the streams are bit-identical)
+__device__ __forceinline__ float philox_to_sample(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f; }
+
+// Launches the FFT form when the shape is one it is built for (power-of-two hop 256 / 512, S <= hop); returns false (and
+// launches nothing) otherwise.  *err receives the launch status.
+bool launch_noise_fft(const NoiseParams &p, hipStream_t s, hipError_t *err);
+
+}  // namespace ddsp_noise

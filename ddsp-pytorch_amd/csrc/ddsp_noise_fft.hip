@@ -1,0 +1,537 @@
+// Filtered noise, in-LDS FFT form, for MI355X (gfx950): the same arithmetic contract as ddsp_noise.hip
+// (model/ddsp/filtered_noise.py:7-53) for power-of-two hops R = 256 / 512, where the direct truncated convolution
+// (R/2 multiply-adds per sample) is several times the cost of doing what the reference itself does (:25-32):
+// zero-pad to N = 2R, multiply spectra, transform back, keep R samples.
+//
+// One WAVEFRONT owns a pair of frames (a, b) at a time and nothing is shared between wavefronts, so the kernel has no
+// workgroup barrier at all (workgroup = 64 threads, 16-18 KB of LDS, up to ten per CU); LDS operations of one wavefront
+// execute in order, which is all the hand-offs between the stages need.
+//
+//   1. impulse responses: irfft of the zero-phase magnitudes (:8-10).  For S = 512 the two frames' Hermitian spectra
+//      are packed as H~a + i H~b and ONE 512-point complex inverse FFT yields z_a + i z_b (both real); other S take
+//      the direct cosine sums of ddsp_noise.hip.  Periodic Hann window (:15), roll/pad/roll (:14,:19-20) -> kk = k_a + i k_b
+//   2. noise: the injected draw or Philox4x32-10 with the SAME counter layout as the direct kernels -> xx = x_a + i x_b
+//   3. two N-point complex FFTs, Cx = FFT(xx), Ck = FFT(kk) (inputs zero above R: the first radix-2 layer is free);
+//      frames are paired signal-with-signal and kernel-with-kernel so that both halves of a packed transform have the
+//      same magnitude (packing x with k would lose ~1e-6 of the kernel spectrum under the 13x larger noise spectrum)
+//   4. Hermitian split + product + re-pack in one pass over the bins:
+//         P[g] = [(A + B)(E + F) - i (A - B)(E - F)] / 4,  A = Cx[g], B = conj Cx[N-g], E = Ck[g], F = conj Ck[N-g]
+//      = X_a K_a + i X_b K_b, then ONE N-point inverse FFT gives y_a + i y_b; the first R samples are kept (:31)
+//   5. coalesced float4 stores (read-modify-write when accumulating into the oscillator's output, decoder.py:132)
+//
+// FFT of N = 64 * R1 points on one wavefront: n = 64 n1 + 8 n2 + n3, k = k1 + R1 k2 + 8 R1 k3;
+//   radix-R1 over n1 in registers (lane = 8 n2 + n3) -> twiddle W_N^(lane k1) -> LDS exchange -> radix-8 over n2
+//   (lane = k1 + R1 n3') -> twiddle W_64^(n3 k2) -> LDS exchange -> radix-8 over n3 (lane = k1 + R1 k2).
+// Twiddles live in registers (computed once per wavefront with sincospi); the exchange addresses are rotated so that
+// both the b64 writes and the b64 reads are bank-conflict free.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "ddsp_hip.h"
+#include "ddsp_internal.h"
+#include "ddsp_noise_common.h"
+
+using namespace ddsp_noise;
+
+namespace {
+
+typedef float2 cf;
+
+__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return make_float2(__fmaf_rn(a.x, b.x, -(a.y * b.y)), __fmaf_rn(a.x, b.y, a.y * b.x)); }
+// a * w for the forward transform, a * conj(w) for the inverse (w always holds the FORWARD twiddle e^{-i theta})
+template <bool INV>
+__device__ __forceinline__ cf cmulw(cf a, cf w)
+{
+    if (!INV) return make_float2(__fmaf_rn(a.x, w.x, -(a.y * w.y)), __fmaf_rn(a.x, w.y, a.y * w.x));
+    return make_float2(__fmaf_rn(a.x, w.x, a.y * w.y), __fmaf_rn(a.y, w.x, -(a.x * w.y)));
+}
+// times -i (forward) / +i (inverse)
+template <bool INV>
+__device__ __forceinline__ cf rot90(cf a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+// times W8^1 = e^{-i pi/4} and W8^3 = e^{-3 i pi/4} (conjugated for the inverse)
+template <bool INV>
+__device__ __forceinline__ cf mul_w8_1(cf a)
+{
+    constexpr float r = 0.70710678118654752f;
+    return INV ? make_float2((a.x - a.y) * r, (a.x + a.y) * r) : make_float2((a.x + a.y) * r, (a.y - a.x) * r);
+}
+template <bool INV>
+__device__ __forceinline__ cf mul_w8_3(cf a)
+{
+    constexpr float r = 0.70710678118654752f;
+    return INV ? make_float2(-(a.x + a.y) * r, (a.x - a.y) * r) : make_float2((a.y - a.x) * r, -(a.x + a.y) * r);
+}
+
+// natural order in, natural order out
+template <bool INV>
+__device__ __forceinline__ void dft4(cf &p0, cf &p1, cf &p2, cf &p3)
+{
+    const cf s0 = cadd(p0, p2), s1 = cadd(p1, p3), d0 = csub(p0, p2), d1 = rot90<INV>(csub(p1, p3));
+    p0 = cadd(s0, s1); p1 = cadd(d0, d1); p2 = csub(s0, s1); p3 = csub(d0, d1);
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft8(cf (&v)[8])
+{
+    cf a0 = cadd(v[0], v[4]), a1 = cadd(v[1], v[5]), a2 = cadd(v[2], v[6]), a3 = cadd(v[3], v[7]);
+    cf b0 = csub(v[0], v[4]), b1 = mul_w8_1<INV>(csub(v[1], v[5])), b2 = rot90<INV>(csub(v[2], v[6])), b3 = mul_w8_3<INV>(csub(v[3], v[7]));
+    dft4<INV>(a0, a1, a2, a3);   // X[0], X[2], X[4], X[6]
+    dft4<INV>(b0, b1, b2, b3);   // X[1], X[3], X[5], X[7]
+    v[0] = a0; v[2] = a1; v[4] = a2; v[6] = a3;
+    v[1] = b0; v[3] = b1; v[5] = b2; v[7] = b3;
+}
+
+// HALFZERO: v[8..15] are zero (a length-N/2 signal zero-padded to N): the first radix-2 layer costs only its twiddles
+template <bool INV, bool HALFZERO>
+__device__ __forceinline__ void dft16(cf (&v)[16])
+{
+    constexpr float C = 0.92387953251128674f, S = 0.38268343236508977f;   // cos, sin of pi/8
+    const cf w1 = make_float2(C, -S), w3 = make_float2(S, -C), w5 = make_float2(-S, -C), w7 = make_float2(-C, -S);
+    cf a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        a[j] = HALFZERO ? v[j] : cadd(v[j], v[j + 8]);
+        b[j] = HALFZERO ? v[j] : csub(v[j], v[j + 8]);
+    }
+    b[1] = cmulw<INV>(b[1], w1);
+    b[2] = mul_w8_1<INV>(b[2]);
+    b[3] = cmulw<INV>(b[3], w3);
+    b[4] = rot90<INV>(b[4]);
+    b[5] = cmulw<INV>(b[5], w5);
+    b[6] = mul_w8_3<INV>(b[6]);
+    b[7] = cmulw<INV>(b[7], w7);
+    dft8<INV>(a);   // X[2m]
+    dft8<INV>(b);   // X[2m+1]
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { v[2 * m] = a[m]; v[2 * m + 1] = b[m]; }
+}
+
+template <int R1, bool INV, bool HALFZERO>
+__device__ __forceinline__ void dft_r1(cf (&v)[R1])
+{
+    if constexpr (R1 == 16) dft16<INV, HALFZERO>(v);
+    else {
+        if constexpr (HALFZERO) {
+            // v[4..7] zero: a_j = v_j, b_j = v_j W8^j
+            cf a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+            cf b0 = v[0], b1 = mul_w8_1<INV>(v[1]), b2 = rot90<INV>(v[2]), b3 = mul_w8_3<INV>(v[3]);
+            dft4<INV>(a0, a1, a2, a3);
+            dft4<INV>(b0, b1, b2, b3);
+            v[0] = a0; v[2] = a1; v[4] = a2; v[6] = a3;
+            v[1] = b0; v[3] = b1; v[5] = b2; v[7] = b3;
+        } else {
+            dft8<INV>(v);
+        }
+    }
+}
+
+// LDS operations of one wavefront execute in order: between a stage's stores and the next stage's loads only the
+// compiler has to be kept from reordering.
+#define DDSP_WAVE_ORDER() do { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+// Per-wavefront twiddles of the 64*R1-point transform (forward values; the inverse conjugates on the fly).
+template <int R1>
+struct Twiddles {
+    cf t1[R1];                 // W_N^(lane * k1)
+    cf t2[R1 / 8][8];          // W_64^(n3 * k2) for the lane's n3 of step 2 (one per DFT the lane does there)
+};
+
+template <int R1>
+__device__ __forceinline__ void make_twiddles(Twiddles<R1> &tw, int lane)
+{
+    constexpr int N = 64 * R1;
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) {
+        float s, c;
+        sincospif(2.0f * (float)((lane * k1) & (N - 1)) / (float)N, &s, &c);
+        tw.t1[k1] = make_float2(c, -s);
+    }
+#pragma unroll
+    for (int d = 0; d < R1 / 8; ++d) {
+        const int n3 = (lane / R1) + (64 / R1) * d;      // step-2 lane = k1 + R1 * (n3 mod (64/R1)), DFT d = n3 div (64/R1)
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) {
+            float s, c;
+            sincospif(2.0f * (float)((n3 * k2) & 63) / 64.0f, &s, &c);
+            tw.t2[d][k2] = make_float2(c, -s);
+        }
+    }
+}
+
+// Exchange addresses (in float2 units inside one N-element buffer).
+// step 1 -> 2: element (k1, n2, n3); rows of 8*R1 per n2, blocks of R1 per n3, rotated inside the block so that the
+// 16 lanes of a b64 write group (two n2, eight n3, one k1) hit 16 different bank pairs.
+template <int R1>
+__device__ __forceinline__ int addr1(int k1, int n2, int n3)
+{
+    const int rot = (R1 == 16) ? (n3 + 8 * (n2 & 1)) : (n3 + (n2 & 1));
+    return n2 * (8 * R1) + R1 * n3 + ((k1 + rot) & (R1 - 1));
+}
+// step 2 -> 3: element (c = k1 + R1 k2, n3): rows of 8*R1 per n3 (R1 = 8: rotated by 8 on odd rows)
+template <int R1>
+__device__ __forceinline__ int addr2(int c, int n3)
+{
+    return n3 * (8 * R1) + ((R1 == 16) ? c : ((c + 8 * (n3 & 1)) & 63));
+}
+
+// 64*R1-point complex FFT of the wavefront's data.  In: v[n1] = x[64 n1 + lane].  Out: v[d * 8 + k3] = X[c + 8 R1 k3] with
+// c = lane + 64 d (d < R1/8).  `buf`: N float2 of LDS, free to clobber.
+template <int R1, bool INV, bool HALFZERO>
+__device__ __forceinline__ void fft_wave(cf (&v)[R1], const Twiddles<R1> &tw, cf *buf, int lane)
+{
+    constexpr int ND = R1 / 8;                     // radix-8 DFTs per lane in steps 2 and 3
+    // step 1: radix-R1 over n1, twiddle, scatter
+    dft_r1<R1, INV, HALFZERO>(v);
+    {
+        const int n2 = lane >> 3, n3 = lane & 7;
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) {
+            const cf a = (k1 == 0) ? v[0] : cmulw<INV>(v[k1], tw.t1[k1]);
+            buf[addr1<R1>(k1, n2, n3)] = a;
+        }
+    }
+    DDSP_WAVE_ORDER();
+    // step 2: radix-8 over n2, twiddle, scatter
+    cf u[ND][8];
+    {
+        const int k1 = lane & (R1 - 1), m3 = lane / R1;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const int n3 = m3 + (64 / R1) * d;
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) u[d][n2] = buf[addr1<R1>(k1, n2, n3)];
+        }
+        DDSP_WAVE_ORDER();
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const int n3 = m3 + (64 / R1) * d;
+            dft8<INV>(u[d]);
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                const cf a = (k2 == 0) ? u[d][0] : cmulw<INV>(u[d][k2], tw.t2[d][k2]);
+                buf[addr2<R1>(k1 + R1 * k2, n3)] = a;
+            }
+        }
+    }
+    DDSP_WAVE_ORDER();
+    // step 3: radix-8 over n3
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const int c = lane + 64 * d;
+        cf t[8];
+#pragma unroll
+        for (int n3 = 0; n3 < 8; ++n3) t[n3] = buf[addr2<R1>(c, n3)];
+        dft8<INV>(t);
+#pragma unroll
+        for (int k3 = 0; k3 < 8; ++k3) v[d * 8 + k3] = t[k3];
+    }
+    DDSP_WAVE_ORDER();
+}
+
+// natural-order store of the result layout of fft_wave
+template <int R1>
+__device__ __forceinline__ void store_natural(const cf (&v)[R1], cf *dst, int lane)
+{
+#pragma unroll
+    for (int d = 0; d < R1 / 8; ++d)
+#pragma unroll
+        for (int k3 = 0; k3 < 8; ++k3) dst[lane + 64 * d + 8 * R1 * k3] = v[d * 8 + k3];
+}
+
+struct FrameSrc {
+    long frame;   // index into [B*T]
+    bool valid;
+};
+
+// ---- the kernel ------------------------------------------------------------------------------------------------
+// R1 = N / 64 = R / 32 (16: hop 512, 8: hop 256).  IRFFT: S == 512, impulse responses by one packed 512-point inverse
+// FFT; otherwise direct cosine sums (any even S <= R).
+template <int R1, bool IRFFT>
+__global__ void __launch_bounds__(64) noise_fft_kernel(NoiseParams p, long npairs)
+{
+    constexpr int N = 64 * R1, R = N / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    cf *bufA = reinterpret_cast<cf *>(smem_f);          // N float2
+    cf *bufB = bufA + N;                                // N float2
+    float *ctab = reinterpret_cast<float *>(bufB + N);  // [S] cos(2 pi m / S) (direct impulse responses only)
+    const int lane = threadIdx.x;
+    const int S = p.S, F = p.F, half = S >> 1;
+    const long nframes = (long)p.B * p.T;
+
+    Twiddles<R1> tw;
+    make_twiddles<R1>(tw, lane);
+    // 512-point transform of the packed impulse responses: its W_512^(lane k1) are the even entries of the N = 1024 table
+    // (or the table itself when N = 512): no registers of their own; only its step-2 twiddles are new
+    Twiddles<8> tw8;
+    if (IRFFT) {
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) tw8.t1[k1] = tw.t1[(R1 / 8) * k1];
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) {
+            float sn, cs;
+            sincospif(2.0f * (float)(((lane >> 3) * k2) & 63) / 64.0f, &sn, &cs);
+            tw8.t2[0][k2] = make_float2(cs, -sn);
+        }
+    } else {
+        for (int m = lane; m < S; m += 64) ctab[m] = cospif((float)(2 * m) / (float)S);
+    }
+    // cos, sin of 2 pi lane / 512 (for the window of z[lane + 64 k3]: 0.5 + 0.5 cos(2 pi lane / 512 + pi k3 / 4))
+    const float win_c = tw.t1[(R1 / 8) * 1].x, win_s = -tw.t1[(R1 / 8) * 1].y;
+    DDSP_WAVE_ORDER();
+    const uint64_t base_off = p.offset + (p.offset_dev ? *p.offset_dev : 0ull);
+    constexpr int quads = R >> 2;
+
+    for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+        FrameSrc fr[2];
+        fr[0].frame = 2 * pair;     fr[0].valid = true;
+        fr[1].frame = 2 * pair + 1; fr[1].valid = fr[1].frame < nframes;
+
+        // ---- 1. impulse responses -> kk[j] = k_a[j] + i k_b[j] in bufB[0, R) ----------------------------------
+        cf h[8];
+        if (IRFFT) {
+            const float *Ha = p.Hm + fr[0].frame * F;
+            const float *Hb = p.Hm + (fr[1].valid ? fr[1].frame : fr[0].frame) * F;
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) {
+                const int f = 64 * n1 + lane;
+                const int src = f <= 256 ? f : 512 - f;          // Hermitian extension of the real, zero-phase spectrum
+                h[n1] = make_float2(Ha[src], fr[1].valid ? Hb[src] : 0.0f);
+            }
+        }
+        if (IRFFT) {
+            fft_wave<8, true, false>(h, tw8, bufB, lane);
+            // z[n] = h[k3] at n = lane + 64 k3; S == R here: kk[n] = z[n] * window(n), window(n) = 0.5 + 0.5 cos(2 pi n / S)
+            // (roll(+S/2), periodic Hann, roll(-S/2)); cos(2 pi lane / 512 + pi k3 / 4) from the lane's twiddle
+            constexpr float r8 = 0.70710678118654752f;
+            const float ck[8] = {1.0f, r8, 0.0f, -r8, -1.0f, -r8, 0.0f, r8}, sk[8] = {0.0f, r8, 1.0f, r8, 0.0f, -r8, -1.0f, -r8};
+#pragma unroll
+            for (int k3 = 0; k3 < 8; ++k3) {
+                const int n = lane + 64 * k3;
+                const int j = n < 256 ? n : n + (R - 512);
+                const float wgt = __fmaf_rn(0.5f, win_c * ck[k3] - win_s * sk[k3], 0.5f) * (1.0f / 512.0f);
+                bufB[j] = make_float2(h[k3].x * wgt, h[k3].y * wgt);
+            }
+            if constexpr (R > 512) {
+                for (int j = 256 + lane; j < R - 256; j += 64) bufB[j] = make_float2(0.0f, 0.0f);
+            }
+        } else {
+            // direct inverse real DFT (ddsp_noise.hip phase 1): z[n] and z[S/2 - n] from one pass over the bins.  The bins
+            // are the same for every lane: they come straight from global memory (wave-uniform addresses -> scalar loads).
+            const float *Ha = p.Hm + fr[0].frame * F;
+            const float *Hb = p.Hm + (fr[1].valid ? fr[1].frame : fr[0].frame) * F;
+            const float vb = fr[1].valid ? 1.0f : 0.0f;
+            for (int j = lane; j < R; j += 64) bufB[j] = make_float2(0.0f, 0.0f);
+            DDSP_WAVE_ORDER();
+            const float invS = 1.0f / (float)S;
+            auto emit = [&](int nn, float za, float zb) {
+#pragma unroll
+                for (int wrap = 0; wrap < 2; ++wrap) {
+                    int src;
+                    if (!wrap) { if (nn == half) continue; src = nn + half; }
+                    else       { if (nn == 0) continue;    src = half - nn; }
+                    const float win = 0.5f - 0.5f * ctab[src];
+                    const int jj = !wrap ? nn : (R - nn);       // S <= R: nn <= S/2 < R
+                    bufB[jj] = make_float2(za * win, zb * vb * win);
+                }
+            };
+            const float h0a = Ha[0], hna = Ha[half], h0b = Hb[0], hnb = Hb[half];
+            // n = 0 and n = S/2 need no cosines (plain and alternating sums): every lane takes the bins k = lane + 1 + 64 r
+            {
+                float ea = 0.0f, oa = 0.0f, eb = 0.0f, ob = 0.0f;
+                for (int k = 1 + lane; k < half; k += 64) {
+                    const float ha = Ha[k], hb = Hb[k];
+                    if (k & 1) { oa += ha; ob += hb; } else { ea += ha; eb += hb; }
+                }
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) {
+                    ea += __shfl_xor(ea, m); oa += __shfl_xor(oa, m); eb += __shfl_xor(eb, m); ob += __shfl_xor(ob, m);
+                }
+                if (lane == 0) {
+                    const float sg = (half & 1) ? -1.0f : 1.0f;
+                    emit(0, __fmaf_rn(2.0f, ea + oa, h0a + hna) * invS, __fmaf_rn(2.0f, eb + ob, h0b + hnb) * invS);
+                    emit(half, __fmaf_rn(2.0f, ea - oa, h0a + sg * hna) * invS, __fmaf_rn(2.0f, eb - ob, h0b + sg * hnb) * invS);
+                }
+            }
+            // n = 1 .. S/4 paired with S/2 - n: cos(2 pi k (S/2 - n) / S) = (-1)^k cos(2 pi k n / S).  Bins two at a time
+            // (odd, even), eight per unrolled step, so that the table reads of a step are in flight together.
+            for (int n0 = 1; n0 <= half / 2; n0 += 64) {
+                const int n = n0 + lane;
+                const bool mine = n <= half / 2;
+                const int nstep = mine ? n : 0;
+                float ea = 0.0f, oa = 0.0f, eb = 0.0f, ob = 0.0f;
+                int idx = 0;
+                int k = 1;
+#pragma unroll 1
+                for (; k + 7 < half; k += 8) {
+                    float c[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        idx += nstep;
+                        if (idx >= S) idx -= S;
+                        c[e] = ctab[idx];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float ha = Ha[k + e], hb = Hb[k + e];
+                        if ((e & 1) == 0) { oa = __fmaf_rn(ha, c[e], oa); ob = __fmaf_rn(hb, c[e], ob); }   // k odd (k starts at 1)
+                        else              { ea = __fmaf_rn(ha, c[e], ea); eb = __fmaf_rn(hb, c[e], eb); }
+                    }
+                }
+                for (; k < half; ++k) {
+                    idx += nstep;
+                    if (idx >= S) idx -= S;
+                    const float c = ctab[idx];
+                    const float ha = Ha[k], hb = Hb[k];
+                    if (k & 1) { oa = __fmaf_rn(ha, c, oa); ob = __fmaf_rn(hb, c, ob); }
+                    else       { ea = __fmaf_rn(ha, c, ea); eb = __fmaf_rn(hb, c, eb); }
+                }
+                if (mine) {
+                    const int n2 = half - n;
+                    const float sg1 = (n & 1) ? -1.0f : 1.0f, sg2 = (n2 & 1) ? -1.0f : 1.0f;
+                    emit(n, __fmaf_rn(2.0f, ea + oa, h0a + sg1 * hna) * invS, __fmaf_rn(2.0f, eb + ob, h0b + sg1 * hnb) * invS);
+                    if (n2 != n) emit(n2, __fmaf_rn(2.0f, ea - oa, h0a + sg2 * hna) * invS, __fmaf_rn(2.0f, eb - ob, h0b + sg2 * hnb) * invS);
+                }
+            }
+        }
+        DDSP_WAVE_ORDER();
+
+        // ---- 2. noise -> xx[m] = x_a[m] + i x_b[m] in bufA[0, R) -------------------------------------------------
+        if (p.u) {
+            const float *ua = p.u + fr[0].frame * R;
+            const float *ub = p.u + (fr[1].valid ? fr[1].frame : fr[0].frame) * R;
+#pragma unroll
+            for (int e = 0; e < quads / 64; ++e) {
+                const int q = lane + 64 * e;
+                const float4 a = *reinterpret_cast<const float4 *>(ua + 4 * q);
+                float4 b = *reinterpret_cast<const float4 *>(ub + 4 * q);
+                if (!fr[1].valid) b = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
+                bufA[4 * q + 0] = make_float2(a.x * 2.0f - 1.0f, b.x * 2.0f - 1.0f);
+                bufA[4 * q + 1] = make_float2(a.y * 2.0f - 1.0f, b.y * 2.0f - 1.0f);
+                bufA[4 * q + 2] = make_float2(a.z * 2.0f - 1.0f, b.z * 2.0f - 1.0f);
+                bufA[4 * q + 3] = make_float2(a.w * 2.0f - 1.0f, b.w * 2.0f - 1.0f);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < quads / 64; ++e) {
+                const int q = lane + 64 * e;
+                uint32_t ra[4], rb[4];
+                const uint64_t ca = base_off + (uint64_t)fr[0].frame * (uint64_t)quads + (uint64_t)q;
+                const uint64_t cb = base_off + (uint64_t)fr[1].frame * (uint64_t)quads + (uint64_t)q;
+                philox4x32_10((uint32_t)ca, (uint32_t)(ca >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32), ra);
+                philox4x32_10((uint32_t)cb, (uint32_t)(cb >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rb);
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) bufA[4 * q + c4] = make_float2(philox_to_sample(ra[c4]), philox_to_sample(rb[c4]));
+            }
+        }
+        DDSP_WAVE_ORDER();
+
+        // ---- 3. Cx = FFT_N(xx), Ck = FFT_N(kk), natural order in bufA / bufB ---------------------------------------
+        cf v[R1];
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) v[n1] = (n1 < R1 / 2) ? bufA[64 * n1 + lane] : make_float2(0.0f, 0.0f);
+        DDSP_WAVE_ORDER();
+        fft_wave<R1, false, true>(v, tw, bufA, lane);
+        store_natural<R1>(v, bufA, lane);
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) v[n1] = (n1 < R1 / 2) ? bufB[64 * n1 + lane] : make_float2(0.0f, 0.0f);
+        DDSP_WAVE_ORDER();
+        fft_wave<R1, false, true>(v, tw, bufB, lane);
+        store_natural<R1>(v, bufB, lane);
+        DDSP_WAVE_ORDER();
+
+        // ---- 4. split, multiply, re-pack; inverse FFT ---------------------------------------------------------------
+#pragma unroll
+        for (int g1 = 0; g1 < R1; ++g1) {
+            const int g = 64 * g1 + lane, gm = (N - g) & (N - 1);
+            const cf A = bufA[g], Bc = bufA[gm], E = bufB[g], Fc = bufB[gm];
+            const cf B = make_float2(Bc.x, -Bc.y), Fk = make_float2(Fc.x, -Fc.y);
+            const cf m1 = cmul(cadd(A, B), cadd(E, Fk));          // 4 X_a K_a
+            const cf m2 = cmul(csub(A, B), csub(E, Fk));          // -4 X_b K_b
+            // P = (m1 - i m2) / 4 ; the 1/(4N) of split + inverse transform is applied at the output
+            v[g1] = make_float2(m1.x + m2.y, m1.y - m2.x);
+        }
+        DDSP_WAVE_ORDER();
+        fft_wave<R1, true, false>(v, tw, bufA, lane);
+
+        // ---- 5. first R samples: y_a = Re, y_b = Im; staged through LDS for whole-line stores ----------------------
+        float *ya = reinterpret_cast<float *>(bufB), *yb = ya + R;
+        constexpr float kScale = 1.0f / (4.0f * (float)N);
+#pragma unroll
+        for (int d = 0; d < R1 / 8; ++d)
+#pragma unroll
+            for (int k3 = 0; k3 < 4; ++k3) {                      // n = c + 8 R1 k3 < R  <=>  k3 < 4
+                const int n = lane + 64 * d + 8 * R1 * k3;
+                ya[n] = v[d * 8 + k3].x * kScale;
+                yb[n] = v[d * 8 + k3].y * kScale;
+            }
+        DDSP_WAVE_ORDER();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (!fr[q].valid) continue;
+            float4 *dst = reinterpret_cast<float4 *>(p.y + fr[q].frame * R);
+            const float4 *src = reinterpret_cast<const float4 *>(q ? yb : ya);
+#pragma unroll
+            for (int e = 0; e < R / 256; ++e) {
+                float4 o = src[lane + 64 * e];
+                if (p.accumulate) {
+                    const float4 a = dst[lane + 64 * e];
+                    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+                }
+                dst[lane + 64 * e] = o;
+            }
+        }
+        DDSP_WAVE_ORDER();
+    }
+}
+
+template <int R1, bool IRFFT>
+hipError_t launch(const NoiseParams &p, hipStream_t s)
+{
+    constexpr int N = 64 * R1;
+    const long nframes = (long)p.B * p.T;
+    const long npairs = (nframes + 1) / 2;
+    const size_t lds = sizeof(float2) * 2 * N + (IRFFT ? 0 : sizeof(float) * (size_t)p.S);
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    static int cached[64] = {};
+    if (!cached[dev & 63]) {
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        cached[dev & 63] = cus;
+    }
+    cus = cached[dev & 63];
+    // wavefronts a CU holds of this kernel: registers allow 2 (R1 = 16) or 4 (R1 = 8) per SIMD, LDS 160 KiB / lds
+    const long by_regs = R1 == 16 ? 8 : 16, by_lds = (160 * 1024) / (long)lds;
+    const long resident = (long)cus * (by_lds < by_regs ? by_lds : by_regs);
+    const long grid = npairs < resident ? npairs : resident;
+    const int slot = ddsp_prof::begin(ddsp_prof::NOISE, s);
+    hipLaunchKernelGGL((noise_fft_kernel<R1, IRFFT>), dim3((unsigned)grid), dim3(64), lds, s, p, npairs);
+    ddsp_prof::end(slot, s);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+namespace ddsp_noise {
+
+bool launch_noise_fft(const NoiseParams &p, hipStream_t s, hipError_t *err)
+{
+    const int R = p.R, S = p.S;
+    if (S > R || (S & 1) || S < 4) return false;                 // hop < 2(F-1) crops the impulse response: direct kernels
+    if (((uintptr_t)p.y % 16) != 0 || (p.u && ((uintptr_t)p.u % 16) != 0)) return false;
+    if (R == 512) {
+        *err = (S == 512) ? launch<16, true>(p, s) : launch<16, false>(p, s);
+        return true;
+    }
+    if (R == 256) {
+        *err = launch<8, false>(p, s);
+        return true;
+    }
+    return false;
+}
+
+}  // namespace ddsp_noise

@@ -189,11 +189,12 @@ def test_cpu_tensors_fail_loudly():
         ddsp.osc_forward(torch.from_numpy(g["f0"]), torch.from_numpy(g["c"]), torch.from_numpy(g["a"]), 64, 16000)
 
 
+@pytest.mark.parametrize("mode", [1, 2])     # 1: one frame per workgroup; 2: batched direct form where the FFT form would run
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "g8_noise_*.npz"))))
-def test_noise_generic_kernel(path):
+def test_noise_generic_kernel(path, mode):
     g = load_golden(os.path.basename(path)[:-4])
     L = ddsp._lib.lib()
-    L.ddsp_noise_set_generic(1)
+    L.ddsp_noise_set_generic(mode)
     try:
         y = ddsp.noise_forward(dev(g["H"]), int(g["hop"]), uniform=dev(g["uniform"]))
     finally:
@@ -202,7 +203,9 @@ def test_noise_generic_kernel(path):
 
 
 @pytest.mark.parametrize("hop,nf,B,T", [(128, 65, 3, 70), (64, 65, 2, 33), (256, 129, 1, 65), (128, 33, 1, 64), (8, 5, 2, 9), (136, 7, 1, 5),
-                                         (512, 257, 1, 37), (512, 195, 2, 19), (1024, 65, 1, 9)])
+                                         (512, 257, 1, 37), (512, 195, 2, 19), (1024, 65, 1, 9),
+                                         # in-LDS FFT form (hop 256 / 512): impulse shorter than the hop (zero gap), tiny filters, odd frame counts
+                                         (512, 129, 2, 9), (512, 3, 1, 5), (512, 256, 1, 3), (256, 65, 3, 7), (256, 128, 1, 1), (256, 2, 1, 2)])
 def test_noise_vs_oracle_ragged_tiles(hop, nf, B, T):
     rng = np.random.default_rng(hop + nf)
     H = syn.controller_range(rng.standard_normal((B, T, nf), dtype=np.float32))
@@ -210,6 +213,28 @@ def test_noise_vs_oracle_ragged_tiles(hop, nf, B, T):
     ref = oracle.noise_forward(H, u, hop)
     y = ddsp.noise_forward(dev(H), hop, uniform=dev(u))
     assert np.max(np.abs(y.cpu().numpy() - ref)) <= 2e-6
+
+
+@pytest.mark.parametrize("hop,nf", [(512, 257), (512, 195), (256, 129), (256, 100)])
+def test_noise_fft_form_equals_direct_form(hop, nf):
+    """The in-LDS FFT form against the direct (time-domain) kernels on the same inputs: the in-kernel Philox draw uses the
+    same counter layout in both (identical noise), so the outputs agree to FFT rounding; accumulate and odd frame counts too."""
+    L = ddsp._lib.lib()
+    rng = np.random.default_rng(hop + nf)
+    B, T = 3, 21                                                   # 63 frames: the last pair is half empty
+    H = dev(syn.controller_range(rng.standard_normal((B, T, nf), dtype=np.float32)))
+    base = torch.randn(B, T * hop, device="cuda")
+    got = ddsp.noise_forward(H, hop, seed=77, offset=12345)
+    acc = ddsp.noise_forward(H, hop, seed=77, offset=12345, out=base.clone(), accumulate=True)
+    L.ddsp_noise_set_generic(2)
+    try:
+        ref = ddsp.noise_forward(H, hop, seed=77, offset=12345)
+    finally:
+        L.ddsp_noise_set_generic(0)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().max()) <= 2e-6 * scale
+    assert float((acc - (base + ref)).abs().max()) <= 2e-6 * scale + 1e-6
+    assert torch.equal(got, ddsp.noise_forward(H, hop, seed=77, offset=12345))       # deterministic
 
 
 # ---- autograd (boundary contract: differentiable w.r.t. c, a, H; train/train.py:33-34) ------------------
