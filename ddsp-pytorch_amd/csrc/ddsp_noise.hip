@@ -547,10 +547,11 @@ int noise_forward_impl(const float *Hmag, const float *uniform, float *y, int B,
     if ((long)B * T >= (1L << 31)) return DDSP_ERANGE;
     hipStream_t s = (hipStream_t)stream;
     const int mode = g_force_generic.load(std::memory_order_relaxed);
-    // power-of-two hops 256 / 512: the in-LDS FFT form (ddsp_noise_fft.hip); mode bit 1 (tests, A/B) keeps the direct forms
+    // hop 512: the in-LDS FFT form (ddsp_noise_fft.hip); mode bit 1 (tests, A/B) keeps the direct forms, bit 2 takes the
+    // FFT form for hop 256 as well (correct there too, just not faster)
     if (!(mode & 3)) {
         hipError_t fe = hipSuccess;
-        if (launch_noise_fft(p, s, &fe)) return (int)fe;
+        if (launch_noise_fft(p, s, (mode & 4) != 0, &fe)) return (int)fe;
     }
     const int lpf_log = pick_lpf_log(F, hop, mode);
     // (the batched kernel stores whole float4s: an output buffer that is not 16-byte aligned takes the generic kernel)

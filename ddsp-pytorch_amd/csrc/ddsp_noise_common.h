@@ -39,8 +39,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // One U[0,1) draw of the in-kernel stream as x = 2u - 1 (same expression order in every kernel: the streams are bit-identical)
 __device__ __forceinline__ float philox_to_sample(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f; }
 
-// Launches the FFT form when the shape is one it is built for (power-of-two hop 256 / 512, S <= hop); returns false (and
-// launches nothing) otherwise.  *err receives the launch status.
-bool launch_noise_fft(const NoiseParams &p, hipStream_t s, hipError_t *err);
+// Launches the FFT form when the shape is one it is built for and faster at (hop 512, S <= hop; with force_fft also hop 256);
+// returns false (and launches nothing) otherwise.  *err receives the launch status.
+bool launch_noise_fft(const NoiseParams &p, hipStream_t s, bool force_fft, hipError_t *err);
 
 }  // namespace ddsp_noise

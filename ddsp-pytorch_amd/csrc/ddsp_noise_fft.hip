@@ -4,7 +4,7 @@
 // zero-pad to N = 2R, multiply spectra, transform back, keep R samples.
 //
 // One WAVEFRONT owns a pair of frames (a, b) at a time and nothing is shared between wavefronts, so the kernel has no
-// workgroup barrier at all (workgroup = 64 threads, 16-18 KB of LDS, up to ten per CU); LDS operations of one wavefront
+// workgroup barrier at all (workgroup = 64 threads, 17 KB of LDS, eight per CU); LDS operations of one wavefront
 // execute in order, which is all the hand-offs between the stages need.
 //
 //   1. impulse responses: irfft of the zero-phase magnitudes (:8-10).  For S = 512 the two frames' Hermitian spectra
@@ -22,11 +22,12 @@
 // FFT of N = 64 * R1 points on one wavefront: n = 64 n1 + 8 n2 + n3, k = k1 + R1 k2 + 8 R1 k3;
 //   radix-R1 over n1 in registers (lane = 8 n2 + n3) -> twiddle W_N^(lane k1) -> LDS exchange -> radix-8 over n2
 //   (lane = k1 + R1 n3') -> twiddle W_64^(n3 k2) -> LDS exchange -> radix-8 over n3 (lane = k1 + R1 k2).
-// Twiddles live in registers (computed once per wavefront with sincospi); the exchange addresses are rotated so that
-// both the b64 writes and the b64 reads are bank-conflict free.
+// Twiddles live in registers (computed once per wavefront with sincospi); the exchange addresses are linear (lane base +
+// immediate offsets) and padded against bank conflicts.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ddsp_hip.h"
 #include "ddsp_internal.h"
@@ -161,21 +162,20 @@ __device__ __forceinline__ void make_twiddles(Twiddles<R1> &tw, int lane)
     }
 }
 
-// Exchange addresses (in float2 units inside one N-element buffer).
-// step 1 -> 2: element (k1, n2, n3); rows of 8*R1 per n2, blocks of R1 per n3, rotated inside the block so that the
-// 16 lanes of a b64 write group (two n2, eight n3, one k1) hit 16 different bank pairs.
+// Exchange addresses (in float2 units inside one buffer of buf_elems<R1>() elements).  Both are LINEAR in their
+// arguments -- lane-dependent base + compile-time offset, so the unrolled loops address LDS with immediates -- and padded
+// so that b64 accesses do not collide on banks:
+// step 1 -> 2: element (k1, n2, n3) at ROW1 n2 + (R1 + 1) n3 + k1.  The 16 lanes of a b64 write group (two n2, eight n3,
+// one k1) differ by (R1 + 1) n3 + ROW1 (n2 & 1) = 16 different residues mod 16 (ROW1 = 136: 8 mod 16; 81: 1 mod 16);
+// the step-2 reads (lanes k1 + R1 m) are consecutive apart from one pad per R1 lanes (at most a 2-way conflict).
+template <int R1> struct Rows { static constexpr int r1 = (R1 == 16) ? 136 : 81, r2 = (R1 == 16) ? 128 : 72; };
 template <int R1>
-__device__ __forceinline__ int addr1(int k1, int n2, int n3)
-{
-    const int rot = (R1 == 16) ? (n3 + 8 * (n2 & 1)) : (n3 + (n2 & 1));
-    return n2 * (8 * R1) + R1 * n3 + ((k1 + rot) & (R1 - 1));
-}
-// step 2 -> 3: element (c = k1 + R1 k2, n3): rows of 8*R1 per n3 (R1 = 8: rotated by 8 on odd rows)
+__device__ __forceinline__ int addr1(int k1, int n2, int n3) { return Rows<R1>::r1 * n2 + (R1 + 1) * n3 + k1; }
+// step 2 -> 3: element (c = k1 + R1 k2, n3) at ROW2 n3 + c (R1 = 8: 72 = 8 mod 16 separates the two n3 of a write group)
 template <int R1>
-__device__ __forceinline__ int addr2(int c, int n3)
-{
-    return n3 * (8 * R1) + ((R1 == 16) ? c : ((c + 8 * (n3 & 1)) & 63));
-}
+__device__ __forceinline__ int addr2(int c, int n3) { return Rows<R1>::r2 * n3 + c; }
+template <int R1>
+constexpr int buf_elems() { return 8 * Rows<R1>::r1 > 64 * R1 ? 8 * Rows<R1>::r1 : 64 * R1; }
 
 // 64*R1-point complex FFT of the wavefront's data.  In: v[n1] = x[64 n1 + lane].  Out: v[d * 8 + k3] = X[c + 8 R1 k3] with
 // c = lane + 64 d (d < R1/8).  `buf`: N float2 of LDS, free to clobber.
@@ -254,9 +254,10 @@ __global__ void __launch_bounds__(64) noise_fft_kernel(NoiseParams p, long npair
 {
     constexpr int N = 64 * R1, R = N / 2;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    cf *bufA = reinterpret_cast<cf *>(smem_f);          // N float2
-    cf *bufB = bufA + N;                                // N float2
-    float *ctab = reinterpret_cast<float *>(bufB + N);  // [S] cos(2 pi m / S) (direct impulse responses only)
+    constexpr int NB = buf_elems<R1>();                 // N float2 + the exchange padding
+    cf *bufA = reinterpret_cast<cf *>(smem_f);
+    cf *bufB = bufA + NB;
+    float *ctab = reinterpret_cast<float *>(bufB + NB); // [S] cos(2 pi m / S) (direct impulse responses only)
     const int lane = threadIdx.x;
     const int S = p.S, F = p.F, half = S >> 1;
     const long nframes = (long)p.B * p.T;
@@ -445,7 +446,7 @@ __global__ void __launch_bounds__(64) noise_fft_kernel(NoiseParams p, long npair
         // ---- 4. split, multiply, re-pack; inverse FFT ---------------------------------------------------------------
 #pragma unroll
         for (int g1 = 0; g1 < R1; ++g1) {
-            const int g = 64 * g1 + lane, gm = (N - g) & (N - 1);
+            const int g = 64 * g1 + lane, gm = (g1 == 0) ? ((N - lane) & (N - 1)) : (N - lane) - 64 * g1;
             const cf A = bufA[g], Bc = bufA[gm], E = bufB[g], Fc = bufB[gm];
             const cf B = make_float2(Bc.x, -Bc.y), Fk = make_float2(Fc.x, -Fc.y);
             const cf m1 = cmul(cadd(A, B), cadd(E, Fk));          // 4 X_a K_a
@@ -490,10 +491,9 @@ __global__ void __launch_bounds__(64) noise_fft_kernel(NoiseParams p, long npair
 template <int R1, bool IRFFT>
 hipError_t launch(const NoiseParams &p, hipStream_t s)
 {
-    constexpr int N = 64 * R1;
     const long nframes = (long)p.B * p.T;
     const long npairs = (nframes + 1) / 2;
-    const size_t lds = sizeof(float2) * 2 * N + (IRFFT ? 0 : sizeof(float) * (size_t)p.S);
+    const size_t lds = sizeof(float2) * 2 * buf_elems<R1>() + (IRFFT ? 0 : sizeof(float) * (size_t)p.S);
     int dev = 0, cus = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -504,9 +504,12 @@ hipError_t launch(const NoiseParams &p, hipStream_t s)
         cached[dev & 63] = cus;
     }
     cus = cached[dev & 63];
-    // wavefronts a CU holds of this kernel: registers allow 2 (R1 = 16) or 4 (R1 = 8) per SIMD, LDS 160 KiB / lds
-    const long by_regs = R1 == 16 ? 8 : 16, by_lds = (160 * 1024) / (long)lds;
-    const long resident = (long)cus * (by_lds < by_regs ? by_lds : by_regs);
+    // wavefronts a CU holds of this kernel: registers allow 3 (R1 = 16: <= 168 VGPRs) or 5 (R1 = 8: <= 96) per SIMD, LDS 160 KiB / lds
+    const long by_regs = R1 == 16 ? 12 : 20, by_lds = (160 * 1024) / (long)lds;
+    long per_cu = by_lds < by_regs ? by_lds : by_regs;
+    if (per_cu > 4) per_cu -= per_cu % 4;    // the same number of wavefronts on each of the CU's four SIMDs (measured: 9 per CU is slower than 8)
+    if (const char *ev = getenv("DDSP_NOISE_FFT_WAVES")) { const long v = atol(ev); if (v > 0 && v < per_cu) per_cu = v; }   // tuning experiments
+    const long resident = (long)cus * per_cu;
     const long grid = npairs < resident ? npairs : resident;
     const int slot = ddsp_prof::begin(ddsp_prof::NOISE, s);
     hipLaunchKernelGGL((noise_fft_kernel<R1, IRFFT>), dim3((unsigned)grid), dim3(64), lds, s, p, npairs);
@@ -518,7 +521,7 @@ hipError_t launch(const NoiseParams &p, hipStream_t s)
 
 namespace ddsp_noise {
 
-bool launch_noise_fft(const NoiseParams &p, hipStream_t s, hipError_t *err)
+bool launch_noise_fft(const NoiseParams &p, hipStream_t s, bool force_fft, hipError_t *err)
 {
     const int R = p.R, S = p.S;
     if (S > R || (S & 1) || S < 4) return false;                 // hop < 2(F-1) crops the impulse response: direct kernels
@@ -527,7 +530,10 @@ bool launch_noise_fft(const NoiseParams &p, hipStream_t s, hipError_t *err)
         *err = (S == 512) ? launch<16, true>(p, s) : launch<16, false>(p, s);
         return true;
     }
-    if (R == 256) {
+    // hop 256 (N = 512: launch<8, false>) works and is tested through this entry, but measures no faster than the direct
+    // batched kernel there (0.31-0.36 ms against 0.27-0.29 ms at batch 512 x 250 frames, F = 129): the direct form's 128
+    // multiply-adds per sample are already cheaper than three 512-point transforms.  Kept for the tests only (force_fft).
+    if (R == 256 && force_fft) {
         *err = launch<8, false>(p, s);
         return true;
     }

@@ -213,6 +213,14 @@ def test_noise_vs_oracle_ragged_tiles(hop, nf, B, T):
     ref = oracle.noise_forward(H, u, hop)
     y = ddsp.noise_forward(dev(H), hop, uniform=dev(u))
     assert np.max(np.abs(y.cpu().numpy() - ref)) <= 2e-6
+    if hop == 256:                                   # the FFT form is not the default at hop 256: take it explicitly as well
+        L = ddsp._lib.lib()
+        L.ddsp_noise_set_generic(4)
+        try:
+            y = ddsp.noise_forward(dev(H), hop, uniform=dev(u))
+        finally:
+            L.ddsp_noise_set_generic(0)
+        assert np.max(np.abs(y.cpu().numpy() - ref)) <= 2e-6
 
 
 @pytest.mark.parametrize("hop,nf", [(512, 257), (512, 195), (256, 129), (256, 100)])
@@ -224,8 +232,13 @@ def test_noise_fft_form_equals_direct_form(hop, nf):
     B, T = 3, 21                                                   # 63 frames: the last pair is half empty
     H = dev(syn.controller_range(rng.standard_normal((B, T, nf), dtype=np.float32)))
     base = torch.randn(B, T * hop, device="cuda")
-    got = ddsp.noise_forward(H, hop, seed=77, offset=12345)
-    acc = ddsp.noise_forward(H, hop, seed=77, offset=12345, out=base.clone(), accumulate=True)
+    L.ddsp_noise_set_generic(4)                                    # FFT form, also at hop 256
+    try:
+        got = ddsp.noise_forward(H, hop, seed=77, offset=12345)
+        acc = ddsp.noise_forward(H, hop, seed=77, offset=12345, out=base.clone(), accumulate=True)
+        again = ddsp.noise_forward(H, hop, seed=77, offset=12345)
+    finally:
+        L.ddsp_noise_set_generic(0)
     L.ddsp_noise_set_generic(2)
     try:
         ref = ddsp.noise_forward(H, hop, seed=77, offset=12345)
@@ -234,7 +247,7 @@ def test_noise_fft_form_equals_direct_form(hop, nf):
     scale = max(1.0, float(ref.abs().max()))
     assert float((got - ref).abs().max()) <= 2e-6 * scale
     assert float((acc - (base + ref)).abs().max()) <= 2e-6 * scale + 1e-6
-    assert torch.equal(got, ddsp.noise_forward(H, hop, seed=77, offset=12345))       # deterministic
+    assert torch.equal(got, again)                                                    # deterministic
 
 
 # ---- autograd (boundary contract: differentiable w.r.t. c, a, H; train/train.py:33-34) ------------------
