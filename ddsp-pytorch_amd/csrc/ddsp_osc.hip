@@ -38,7 +38,7 @@ namespace {
 // osc_synth_kernel).  NS consecutive samples are advanced per iteration: a stage then covers NS*KL independent
 // instructions, which keeps the short walks (KL = K/4, K/2) from stalling on the latency of the previous stage;
 // only the fp64 accumulate is carried from sample to sample.  (segment lengths must be multiples of NS)
-template <int K, int MODE, bool POW2, int KL = K, int NS = 1>
+template <int K, int MODE, bool POW2, int KL = K, int NS = 1, bool QREUSE = false>
 __device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st, int b, int t, int j, bool active,
                                           int i0, float L0, float L1, int n_beg, int n_end)
 {
@@ -62,7 +62,10 @@ __device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st,
     // writes and the group's reads -- only the compiler must not reorder them.  (A wavefront-scope fence here also
     // waits for the global stores of the previous flush: measured 2x slowdown of the short walks.)
 #define DDSP_WAVE_ORDER() do { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
-    for (int n = n_beg; n < n_end; n += NS) {
+    // QKEEP: full-width synthesis walks (one sample per iteration) compute the modulo's quotient on every other sample only
+    constexpr bool QKEEP = QREUSE && (MODE == MODE_SYNTH) && POW2 && NS == 1;
+    float qk[QKEEP ? KL : 1];
+    auto one_step = [&](int n, const bool fresh) {
         float w0[NS], w1[NS];
 #pragma unroll
         for (int e = 0; e < NS; ++e) {
@@ -109,16 +112,28 @@ __device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st,
             // P - q*2pi32 is exact in fp32 for q = rint(P/2pi32 +- 0.25) < 2^21: r in (-4.8, 4.8).  Taking the
             // nearest multiple instead of the floor changes sin(r) by <= |2pi32 - 2pi| = 1.75e-7.
             float q[NS][KL];
+            if (fresh) {   // wave-uniform
 #pragma unroll
-            for (int e = 0; e < NS; ++e)
+                for (int e = 0; e < NS; ++e)
 #pragma unroll
-                for (int m = 0; m < KL; ++m) q[e][m] = __fmaf_rn(v[e][m], kInvTwoPi32, kRoundMagic);
-            DDSP_STAGE_END();
+                    for (int m = 0; m < KL; ++m) q[e][m] = __fmaf_rn(v[e][m], kInvTwoPi32, kRoundMagic);
+                DDSP_STAGE_END();
 #pragma unroll
-            for (int e = 0; e < NS; ++e)
+                for (int e = 0; e < NS; ++e)
 #pragma unroll
-                for (int m = 0; m < KL; ++m) q[e][m] = q[e][m] - kRoundMagic;
-            DDSP_STAGE_END();
+                    for (int m = 0; m < KL; ++m) q[e][m] = q[e][m] - kRoundMagic;
+                DDSP_STAGE_END();
+                if (QKEEP) {
+#pragma unroll
+                    for (int m = 0; m < KL; ++m) qk[m] = q[0][m];
+                }
+            } else {
+                // The previous sample's quotient: below Nyquist the phase advanced by at most pi since then, so
+                // r = P - q*2pi32 stays in (-pi, 2 pi] -- still a multiple of 2^-21 below 8, i.e. exact -- and v_sin_f32
+                // takes any argument within +-256 revolutions.  Saves the two rounding instructions every other sample.
+#pragma unroll
+                for (int m = 0; m < KL; ++m) q[0][m] = qk[m];
+            }
 #pragma unroll
             for (int e = 0; e < NS; ++e)
 #pragma unroll
@@ -196,7 +211,9 @@ __device__ __forceinline__ void walk_fast(const OscParams &p, FrameState<K> &st,
                 }
             }
         }
-    }
+    };
+    // (one copy of the body, the choice is a scalar branch: two unrolled copies cost 30 more VGPRs and a wavefront per SIMD)
+    for (int n = n_beg; n < n_end; n += NS) one_step(n, !QKEEP || ((n - n_beg) & 1) == 0);
 #undef DDSP_STAGE_END
 #undef DDSP_WAVE_ORDER
 }
@@ -404,8 +421,10 @@ __global__ void __launch_bounds__(256, (SKIP && K <= 13) ? 3 : 1) osc_synth_kern
             // The fast modulo needs 0 <= P < kFastPhaseLimit over the whole frame: increments of the three
             // bracketing frames non-negative (phases then grow monotonically) and the end-of-frame bound small.
             const float xa = wb[(long)ia * p.H + h], xb = wb[(long)ib * p.H + h], xc = wb[(long)ic * p.H + h];
-            const float bound = (float)st.acc[m] + (float)p.R * fmaxf(fmaxf(xa, xb), xc) * 1.0001f;
-            fast = fast && (xa >= 0.0f) && (xb >= 0.0f) && (xc >= 0.0f) && (st.acc[m] >= 0.0) && (bound < kFastPhaseLimit);
+            const float xmax = fmaxf(fmaxf(xa, xb), xc);
+            const float bound = (float)st.acc[m] + (float)p.R * xmax * 1.0001f;
+            // (xmax: a quotient reused for the next sample leaves |r| <= pi + increment; v_sin_f32 wants |r| < 256 * 2 pi)
+            fast = fast && (xa >= 0.0f) && (xb >= 0.0f) && (xc >= 0.0f) && (st.acc[m] >= 0.0) && (bound < kFastPhaseLimit) && (xmax < 1024.0f);
         }
     }
     fast = __all(fast);  // wave-uniform
@@ -436,10 +455,10 @@ __global__ void __launch_bounds__(256, (SKIP && K <= 13) ? 3 : 1) osc_synth_kern
 #define DDSP_WALK2(KL, NS)                                                                                   \
         do {                                                                                                 \
             load_synth_segment<K>(p, st, b, j, ia, t == 0 ? ic : ib, L0, L1);   /* frame 0 clamps to source 0 but keeps neighbour 1 */                                              \
-            if (POW2) walk_fast<K, MODE_SYNTH, true, KL, NS>(p, st, b, t, j, active, ia, L0, L1, 0, p.R >> 1);   \
+            if (POW2) walk_fast<K, MODE_SYNTH, true, KL, NS, !SKIP>(p, st, b, t, j, active, ia, L0, L1, 0, p.R >> 1);   \
             else      walk_fast<K, MODE_SYNTH, false, KL, 1>(p, st, b, t, j, active, ia, L0, L1, 0, split);  \
             load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);                                              \
-            if (POW2) walk_fast<K, MODE_SYNTH, true, KL, NS>(p, st, b, t, j, active, ib, L0, L1, p.R >> 1, p.R); \
+            if (POW2) walk_fast<K, MODE_SYNTH, true, KL, NS, !SKIP>(p, st, b, t, j, active, ib, L0, L1, p.R >> 1, p.R); \
             else      walk_fast<K, MODE_SYNTH, false, KL, 1>(p, st, b, t, j, active, ib, L0, L1, split, p.R); \
         } while (0)
         // short walks advance 4 / 2 samples per iteration (the SKIP kernel is only launched for hop >= 8)

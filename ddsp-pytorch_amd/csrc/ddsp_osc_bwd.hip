@@ -46,6 +46,7 @@ __device__ __forceinline__ void walk_bwd(const OscParams &p, FrameState<K> &st, 
     }
     // stage-ordered like the forward synth walk (ddsp_osc.hip: walk_fast): one instruction type at a time over the K harmonics
 #define DDSP_STAGE_END() __builtin_amdgcn_sched_barrier(0)
+    float qk[KL];
     for (int n = n_beg; n < n_end; ++n) {
         float w0, w1;
         if (POW2) {
@@ -79,15 +80,17 @@ __device__ __forceinline__ void walk_bwd(const OscParams &p, FrameState<K> &st, 
 #pragma unroll
             for (int m = 0; m < KL; ++m) v[m] = remainder_two_pi_call(v[m]);
         } else {
-            float q[KL];
+            // the modulo's quotient is computed on every other sample and reused for the next one (ddsp_osc.hip: walk_fast)
+            if (!POW2 || ((n - n_beg) & 1) == 0) {   // wave-uniform
 #pragma unroll
-            for (int m = 0; m < KL; ++m) q[m] = __fmaf_rn(v[m], kInvTwoPi32, kRoundMagic);
-            DDSP_STAGE_END();
+                for (int m = 0; m < KL; ++m) qk[m] = __fmaf_rn(v[m], kInvTwoPi32, kRoundMagic);
+                DDSP_STAGE_END();
 #pragma unroll
-            for (int m = 0; m < KL; ++m) q[m] = q[m] - kRoundMagic;
-            DDSP_STAGE_END();
+                for (int m = 0; m < KL; ++m) qk[m] = qk[m] - kRoundMagic;
+                DDSP_STAGE_END();
+            }
 #pragma unroll
-            for (int m = 0; m < KL; ++m) v[m] = __fmaf_rn(-q[m], kTwoPi32, v[m]);
+            for (int m = 0; m < KL; ++m) v[m] = __fmaf_rn(-qk[m], kTwoPi32, v[m]);
         }
         DDSP_STAGE_END();
 #pragma unroll
@@ -154,8 +157,9 @@ __global__ void __launch_bounds__(256) osc_bwd_kernel(OscParams p, int use_lds)
         if (h < p.H) {
             st.acc[m] = p.loc[((long)b * p.T + t) * p.H + h] + p.sup[((long)b * p.NSB + sb) * p.H + h];
             const float xa = wb[(long)ia * p.H + h], xb = wb[(long)ib * p.H + h], xc = wb[(long)ic * p.H + h];
-            const float bound = (float)st.acc[m] + (float)p.R * fmaxf(fmaxf(xa, xb), xc) * 1.0001f;
-            fast = fast && (xa >= 0.0f) && (xb >= 0.0f) && (xc >= 0.0f) && (st.acc[m] >= 0.0) && (bound < kFastPhaseLimit);
+            const float xmax = fmaxf(fmaxf(xa, xb), xc);
+            const float bound = (float)st.acc[m] + (float)p.R * xmax * 1.0001f;
+            fast = fast && (xa >= 0.0f) && (xb >= 0.0f) && (xc >= 0.0f) && (st.acc[m] >= 0.0) && (bound < kFastPhaseLimit) && (xmax < 1024.0f);
         }
     }
     fast = __all(fast);
