@@ -59,6 +59,7 @@ from ddsp_pytorch_amd import synthetic as syn  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TLANEOPS = 78.6      # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (= 157.3 TFLOP/s fp32 vector / 2)
+SYNTH_OPS = 11                 # VALU instructions of the synth kernel per harmonic-sample (12 and 10 on alternate samples)
 
 
 class Conf:
@@ -306,9 +307,9 @@ def main():
                          "algorithmic_bytes_per_launch": launch_samples * bytes_per_sample,
                          "algorithmic_bytes_per_sample": bytes_per_sample, "avg_launch_ms": synth_ms,
                          "note": "kernel is VALU-bound (SURVEY §8d): see valu",
-                         "valu": {"harmonic_samples_per_s": hs_per_s, "lane_ops_per_harmonic_sample": 12,
-                                  "achieved_Tlaneops": hs_per_s * 12 / 1e12, "peak_Tlaneops": VALU_PEAK_TLANEOPS,
-                                  "frac": hs_per_s * 12 / 1e12 / VALU_PEAK_TLANEOPS},
+                         "valu": {"harmonic_samples_per_s": hs_per_s, "lane_ops_per_harmonic_sample": SYNTH_OPS,
+                                  "achieved_Tlaneops": hs_per_s * SYNTH_OPS / 1e12, "peak_Tlaneops": VALU_PEAK_TLANEOPS,
+                                  "frac": hs_per_s * SYNTH_OPS / 1e12 / VALU_PEAK_TLANEOPS},
                          "noise_frame": {"bound": "hbm", "kernel": "noise_frame", "achieved": noise_achieved, "peak": HBM_PEAK_GBS,
                                          "unit": "GB/s", "frac": noise_achieved / HBM_PEAK_GBS, "traffic": traffic_of("noise_batched_kernel"),
                                          "algorithmic_bytes_per_launch": launch_samples * noise_bps,

@@ -7,8 +7,9 @@ and a data-parallel step with ONE flat RCCL all-reduce of the gradients.
   fixture can be produced for it).
 * The reference trains on a single GPU (train/train.py:50); the data-parallel step is new design:
   replicas, per-rank batch shard, gradients flattened into one bucket (19.35 MB for the 16 kHz/100/65
-  decoder) and averaged with a single all_reduce -- on 8 MI355X a ring moves 2*7/8 of the bucket per GPU over
-  xGMI, latency- not bandwidth-bound, so one bucket beats many.
+  decoder) and averaged with a single all_reduce.  Design estimate, NOT measured (no run on more than one
+  physical GPU exists yet; two-process tests on one GPU cover correctness only): on 8 MI355X a ring moves
+  2*7/8 of the bucket per GPU over xGMI, which should be latency- rather than bandwidth-bound -- hence one bucket.
 """
 from __future__ import annotations
 
