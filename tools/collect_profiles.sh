@@ -12,5 +12,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_write.err"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_sq.err"
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+# the N > 1 path at the full shape, rehearsed on this ONE GPU (two ranks on cuda:0, gloo): correctness of the launch path, not a scaling figure
+python3 bench.py --gpus 2 --backend gloo --one-device --steps 10 --warmup 3 > "$OUT/bench_two_ranks_one_gpu.json" 2> "$OUT/bench_two_ranks.err"
 python3 tools/summarise_profiles.py "$OUT" "$ROUND" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
