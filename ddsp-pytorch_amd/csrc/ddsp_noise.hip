@@ -101,14 +101,17 @@ constexpr int kNT = 512;       // threads per workgroup
 __device__ __forceinline__ int kern_stride(int R) { return R + 4; }
 __device__ __forceinline__ int xs_stride(int R) { return R + 12; }
 
+// LPFLOG = log2(lanes per frame) is a template parameter so that the H tile's row stride is a compile-time constant (the
+// unrolled cosine sums then address LDS with immediate offsets); SPOW2: S is a power of two (table index by masking).
+template <int LPFLOG, bool SPOW2>
 __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int S = p.S, R = p.R, F = p.F, half = S >> 1;
     const int KS = kern_stride(R), XS = xs_stride(R);
-    const int LPF = 1 << p.lpf_log;                     // lanes per frame in the convolution phase
-    const int FB = 64 >> p.lpf_log;                     // frames per workgroup
-    const int HS = FB + 4;                              // row stride of the transposed H tile
+    constexpr int LPF = 1 << LPFLOG;                    // lanes per frame in the convolution phase
+    constexpr int FB = 64 >> LPFLOG;                    // frames per workgroup
+    constexpr int HS = FB + 4;                          // row stride of the transposed H tile
     float *ct = smem;                                   // [S] (rounded up to a multiple of 4)
     float *kern = ct + ((S + 3) & ~3);                  // [FB][KS]
     float *un = kern + FB * KS;                         // union: Hs [F][HS]  |  xs [FB][XS]
@@ -118,11 +121,9 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
     const long nframes = (long)p.B * p.T;
     const int nf = (int)min((long)FB, nframes - frame0);
 
-    // phase 0
-    for (int e = tid; e < FB * F; e += kNT) {
-        const int f = e / F, k = e - f * F;              // coalesced global read, transposed (padded) LDS write
-        Hs[k * HS + f] = (f < nf) ? p.Hm[(frame0 + f) * F + k] : 0.0f;
-    }
+    // phase 0: a wavefront per frame row (coalesced global read, transposed padded LDS write; no index division)
+    for (int f = tid >> 6; f < FB; f += kNT / 64)
+        for (int k = tid & 63; k < F; k += 64) Hs[k * HS + f] = (f < nf) ? p.Hm[(frame0 + f) * F + k] : 0.0f;
     for (int m = tid; m < S; m += kNT) ct[m] = cospif((float)(2 * m) / (float)S);
     if (S < R)                                          // otherwise phase 1 writes every tap
         for (int e = tid; e < FB * KS; e += kNT) kern[e] = 0.0f;
@@ -132,7 +133,7 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
     const int taps = min(S, R);
     const float invS = 1.0f / (float)S;
     // z[nn] (nn in [0, S/2], = z[S-nn]) of frame f goes, windowed, where roll/pad/roll put samples nn and S-nn
-    auto emit = [&](int f, int nn, float z) {
+    auto emit_general = [&](int f, int nn, float z) {
 #pragma unroll
         for (int wrap = 0; wrap < 2; ++wrap) {
             // roll(z, S/2)[src] holds z[(src + S/2) % S]: z[nn] sits at src = nn + S/2 and src = S/2 - nn
@@ -147,6 +148,18 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
             else if (nn < R) jj = R - nn;
             else jj = (R - nn % R) % R;
             kern[f * KS + jj] = z * win;
+        }
+    };
+    // No crop (S <= R, the normal case): both copies of z[nn] -- at j = nn and at j = R - nn -- carry the same window
+    // weight, 0.5 - 0.5 cos(2 pi (nn +- S/2) / S) = 0.5 + 0.5 cos(2 pi nn / S): one table read, two stores.
+    const bool nocrop = S <= R;
+    auto emit = [&](int f, int nn, float z) {
+        if (nocrop) {   // wave-uniform
+            const float v = z * __fmaf_rn(0.5f, ct[nn], 0.5f);     // nn = S/2: cos = -1, weight 0 (the reference's hann[0])
+            if (nn != half) kern[f * KS + nn] = v;
+            if (nn != 0) kern[f * KS + R - nn] = v;
+        } else {
+            emit_general(f, nn, z);
         }
     };
     {
@@ -172,12 +185,33 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
             const int fq = item / nmain, n = 1 + item - fq * nmain;  // n fastest: a wavefront's H reads broadcast
             float ev[4] = {0, 0, 0, 0}, ov[4] = {0, 0, 0, 0};
             int idx = 0;
-#pragma unroll 4
-            for (int k = 1; k < half; ++k) {
+            const float *hp = &Hs[HS + 4 * fq];                      // bin k = 1
+            int k = 1;
+            // eight bins per trip: the eight table reads and the eight H reads (immediate offsets) are in flight together
+#pragma unroll 1
+            for (; k + 7 < half; k += 8, hp += 8 * HS) {
+                float c[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    idx += n;
+                    if (SPOW2) idx &= S - 1; else if (idx >= S) idx -= S;
+                    c[e] = ct[idx];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float4 h = *reinterpret_cast<const float4 *>(hp + e * HS);
+                    if ((e & 1) == 0) {   // k odd (the trip starts at an odd bin)
+                        ov[0] = __fmaf_rn(h.x, c[e], ov[0]); ov[1] = __fmaf_rn(h.y, c[e], ov[1]); ov[2] = __fmaf_rn(h.z, c[e], ov[2]); ov[3] = __fmaf_rn(h.w, c[e], ov[3]);
+                    } else {
+                        ev[0] = __fmaf_rn(h.x, c[e], ev[0]); ev[1] = __fmaf_rn(h.y, c[e], ev[1]); ev[2] = __fmaf_rn(h.z, c[e], ev[2]); ev[3] = __fmaf_rn(h.w, c[e], ev[3]);
+                    }
+                }
+            }
+            for (; k < half; ++k, hp += HS) {
                 idx += n;
-                if (idx >= S) idx -= S;
+                if (SPOW2) idx &= S - 1; else if (idx >= S) idx -= S;
                 const float c = ct[idx];
-                const float4 h = *reinterpret_cast<const float4 *>(&Hs[k * HS + 4 * fq]);
+                const float4 h = *reinterpret_cast<const float4 *>(hp);
                 if (k & 1) { ov[0] = __fmaf_rn(h.x, c, ov[0]); ov[1] = __fmaf_rn(h.y, c, ov[1]); ov[2] = __fmaf_rn(h.z, c, ov[2]); ov[3] = __fmaf_rn(h.w, c, ov[3]); }
                 else       { ev[0] = __fmaf_rn(h.x, c, ev[0]); ev[1] = __fmaf_rn(h.y, c, ev[1]); ev[2] = __fmaf_rn(h.z, c, ev[2]); ev[3] = __fmaf_rn(h.w, c, ev[3]); }
             }
@@ -198,14 +232,13 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
     // phase 2 (overwrites the H tile)
     for (int e = tid; e < FB * 8; e += kNT) xs[(e >> 3) * XS + (e & 7)] = 0.0f;
     if (p.u) {
-        for (int e = tid; e < FB * R; e += kNT) {
-            const int f = e / R, m = e - f * R;
-            xs[f * XS + 8 + m] = (f < nf) ? p.u[(frame0 + f) * R + m] * 2.0f - 1.0f : 0.0f;
-        }
+        for (int f = tid >> 6; f < FB; f += kNT / 64)                     // a wavefront per frame row: no index division
+            for (int m = tid & 63; m < R; m += 64) xs[f * XS + 8 + m] = (f < nf) ? p.u[(frame0 + f) * R + m] * 2.0f - 1.0f : 0.0f;
     } else {
         const int quads = R >> 2;                        // R % 8 == 0 here
+        const int qshift = (quads & (quads - 1)) == 0 ? __builtin_ctz(quads) : -1;    // power-of-two hops: shift instead of divide
         for (int e = tid; e < FB * quads; e += kNT) {
-            const int f = e / quads, q = e - f * quads;
+            const int f = qshift >= 0 ? (e >> qshift) : e / quads, q = e - f * quads;
             const uint64_t ctr = p.offset + (p.offset_dev ? *p.offset_dev : 0ull) + (uint64_t)(frame0 + f) * (uint64_t)quads + (uint64_t)q;
             uint32_t r[4];
             philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r);
@@ -221,8 +254,8 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
 
     // phase 3: lane = (frame, sub-chunk); a wavefront owns the groups q and Q-1-q of LPF consecutive 8-sample chunks
     const int lane = tid & 63, wv = tid >> 6;
-    const int fr = lane >> p.lpf_log, sub = lane & (LPF - 1);
-    const int C = R >> 3, Q = (C + LPF - 1) >> p.lpf_log;
+    const int fr = lane >> LPFLOG, sub = lane & (LPF - 1);
+    const int C = R >> 3, Q = (C + LPF - 1) >> LPFLOG;
     const float *krow = kern + fr * KS;
     const float *xrow = xs + fr * XS + 8;
     float *yrow = p.y + (frame0 + fr) * R;
@@ -558,14 +591,30 @@ int noise_forward_impl(const float *Hmag, const float *uniform, float *y, int B,
     if (!(mode & 1) && hop % 8 == 0 && lpf_log >= 0 && ((uintptr_t)y % 16) == 0) {
         const size_t blds = batched_lds_bytes(F, hop, lpf_log);
         p.lpf_log = lpf_log;
-        static bool attr_set[64] = {};
-        const hipError_t ae = ddsp_allow_big_lds((const void *)noise_batched_kernel, attr_set);
-        if (ae != hipSuccess) return (int)ae;
         const int fb = 64 >> lpf_log;
         const long blocks = ((long)B * T + fb - 1) / fb;
-        const int slot = ddsp_prof::begin(ddsp_prof::NOISE, s);
-        hipLaunchKernelGGL(noise_batched_kernel, dim3((unsigned)blocks), dim3(kNT), blds, s, p);
-        ddsp_prof::end(slot, s);
+        const bool spow2 = (p.S & (p.S - 1)) == 0;
+        hipError_t le = hipSuccess;
+#define DDSP_NOISE_LAUNCH(L, P2)                                                                                       \
+        do {                                                                                                           \
+            static bool attr_set[64] = {};                                                                             \
+            le = ddsp_allow_big_lds((const void *)noise_batched_kernel<L, P2>, attr_set);                              \
+            if (le != hipSuccess) return (int)le;                                                                      \
+            const int slot = ddsp_prof::begin(ddsp_prof::NOISE, s);                                                    \
+            hipLaunchKernelGGL((noise_batched_kernel<L, P2>), dim3((unsigned)blocks), dim3(kNT), blds, s, p);          \
+            ddsp_prof::end(slot, s);                                                                                   \
+        } while (0)
+        switch (lpf_log * 2 + (spow2 ? 1 : 0)) {
+            case 0: DDSP_NOISE_LAUNCH(0, false); break;
+            case 1: DDSP_NOISE_LAUNCH(0, true); break;
+            case 2: DDSP_NOISE_LAUNCH(1, false); break;
+            case 3: DDSP_NOISE_LAUNCH(1, true); break;
+            case 4: DDSP_NOISE_LAUNCH(2, false); break;
+            case 5: DDSP_NOISE_LAUNCH(2, true); break;
+            case 6: DDSP_NOISE_LAUNCH(3, false); break;
+            default: DDSP_NOISE_LAUNCH(3, true); break;
+        }
+#undef DDSP_NOISE_LAUNCH
         return (int)hipGetLastError();
     }
     const size_t lds = sizeof(float) * ((size_t)F + p.S + 2 * (size_t)hop);
