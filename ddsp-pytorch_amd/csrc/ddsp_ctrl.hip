@@ -67,9 +67,39 @@ __device__ __forceinline__ float wave_sum64(float v)
     return v;
 }
 
-template <int NV>
-__global__ void __launch_bounds__(256) ln_lrelu_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
-                                                           const float *__restrict__ beta, float *__restrict__ y,
+// Element type of the activations (x, y and their gradients): fp32, or -- under torch.autocast, where the Linear in front
+// hands over bf16 / fp16 and the Linear behind wants it back -- the 16-bit type itself, so that no cast pass runs on either
+// side of the fused pass.  Statistics, gamma / beta and all arithmetic stay fp32.
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+struct IoF32 {
+    typedef float T;
+    static __device__ __forceinline__ float4 ld(const T *p, long i) { return reinterpret_cast<const float4 *>(p)[i]; }
+    static __device__ __forceinline__ void st(T *p, long i, float4 v) { reinterpret_cast<float4 *>(p)[i] = v; }
+};
+template <typename V4, typename E>
+struct IoHalf {
+    typedef E T;
+    static __device__ __forceinline__ float4 ld(const T *p, long i)
+    {
+        const V4 h = reinterpret_cast<const V4 *>(p)[i];
+        const f32x4_t f = __builtin_convertvector(h, f32x4_t);
+        return make_float4(f.x, f.y, f.z, f.w);
+    }
+    static __device__ __forceinline__ void st(T *p, long i, float4 v)
+    {
+        const f32x4_t f = {v.x, v.y, v.z, v.w};
+        reinterpret_cast<V4 *>(p)[i] = __builtin_convertvector(f, V4);     // round to nearest even
+    }
+};
+typedef IoHalf<bf16x4_t, __bf16> IoBf16;
+typedef IoHalf<f16x4_t, _Float16> IoF16;
+
+template <int NV, typename IO>
+__global__ void __launch_bounds__(256) ln_lrelu_fwd_kernel(const typename IO::T *__restrict__ x, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, typename IO::T *__restrict__ y,
                                                            float *__restrict__ mean_out, float *__restrict__ rstd_out,
                                                            long rows, float eps, float slope)
 {
@@ -86,7 +116,7 @@ __global__ void __launch_bounds__(256) ln_lrelu_fwd_kernel(const float *__restri
         float s = 0.0f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            v[j] = reinterpret_cast<const float4 *>(x + row * D)[lane + 64 * j];
+            v[j] = IO::ld(x + row * D, lane + 64 * j);
             s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         }
         const float mean = wave_sum64(s) * (1.0f / D);
@@ -108,18 +138,18 @@ __global__ void __launch_bounds__(256) ln_lrelu_fwd_kernel(const float *__restri
             o.y = o.y > 0.0f ? o.y : o.y * slope;
             o.z = o.z > 0.0f ? o.z : o.z * slope;
             o.w = o.w > 0.0f ? o.w : o.w * slope;
-            reinterpret_cast<float4 *>(y + row * D)[lane + 64 * j] = o;
+            IO::st(y + row * D, lane + 64 * j, o);
         }
         if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
     }
 }
 
 // partials: [gridDim.x][2][D]  (d gamma | d beta), one slab per workgroup, summed over its four wavefronts through LDS
-template <int NV>
-__global__ void __launch_bounds__(256) ln_lrelu_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ x,
-                                                           const float *__restrict__ y, const float *__restrict__ gamma,
+template <int NV, typename IO>
+__global__ void __launch_bounds__(256) ln_lrelu_bwd_kernel(const typename IO::T *__restrict__ gy, const typename IO::T *__restrict__ x,
+                                                           const typename IO::T *__restrict__ y, const float *__restrict__ gamma,
                                                            const float *__restrict__ mean_in, const float *__restrict__ rstd_in,
-                                                           float *__restrict__ gx, float *__restrict__ partials, long rows, float slope)
+                                                           typename IO::T *__restrict__ gx, float *__restrict__ partials, long rows, float slope)
 {
     constexpr int D = 256 * NV;
     __shared__ float red[4][2][D];
@@ -136,9 +166,9 @@ __global__ void __launch_bounds__(256) ln_lrelu_bwd_kernel(const float *__restri
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const float4 xv = reinterpret_cast<const float4 *>(x + row * D)[lane + 64 * j];
-            const float4 yv = reinterpret_cast<const float4 *>(y + row * D)[lane + 64 * j];
-            float4 gv = reinterpret_cast<const float4 *>(gy + row * D)[lane + 64 * j];
+            const float4 xv = IO::ld(x + row * D, lane + 64 * j);
+            const float4 yv = IO::ld(y + row * D, lane + 64 * j);
+            float4 gv = IO::ld(gy + row * D, lane + 64 * j);
             gv.x = yv.x > 0.0f ? gv.x : gv.x * slope;      // the activation keeps the sign of its input (slope > 0)
             gv.y = yv.y > 0.0f ? gv.y : gv.y * slope;
             gv.z = yv.z > 0.0f ? gv.z : gv.z * slope;
@@ -158,7 +188,7 @@ __global__ void __launch_bounds__(256) ln_lrelu_bwd_kernel(const float *__restri
             o.y = rstd * (d[j].y - m1 - xh[j].y * m2);
             o.z = rstd * (d[j].z - m1 - xh[j].z * m2);
             o.w = rstd * (d[j].w - m1 - xh[j].w * m2);
-            reinterpret_cast<float4 *>(gx + row * D)[lane + 64 * j] = o;
+            IO::st(gx + row * D, lane + 64 * j, o);
         }
     }
 #pragma unroll
@@ -204,47 +234,87 @@ constexpr int kLnBlocks = 1024;  // four workgroups per CU: enough rows in fligh
 
 extern "C" size_t ddsp_ln_lrelu_scratch_bytes(int D) { return D > 0 ? sizeof(float) * 2 * (size_t)D * kLnBlocks : 0; }
 
-extern "C" int ddsp_ln_lrelu_forward(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd,
-                                     long rows, int D, float eps, float slope, void *stream)
+namespace {
+
+template <typename IO>
+int ln_forward(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd, long rows, int D, float eps,
+               float slope, hipStream_t s)
 {
     if (rows == 0) return 0;
     if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 0) return DDSP_EINVAL;
     if (D <= 0 || D % 256 != 0 || D > 1024) return DDSP_ERANGE;
+    typedef typename IO::T T;
+    const T *xi = (const T *)x;
+    T *yo = (T *)y;
     const long want = (rows + 3) / 4;
     const dim3 grid((unsigned)(want < 4096 ? want : 4096)), blk(256);
-    hipStream_t s = (hipStream_t)stream;
     switch (D / 256) {
-        case 1: hipLaunchKernelGGL(ln_lrelu_fwd_kernel<1>, grid, blk, 0, s, x, gamma, beta, y, mean, rstd, rows, eps, slope); break;
-        case 2: hipLaunchKernelGGL(ln_lrelu_fwd_kernel<2>, grid, blk, 0, s, x, gamma, beta, y, mean, rstd, rows, eps, slope); break;
-        case 3: hipLaunchKernelGGL(ln_lrelu_fwd_kernel<3>, grid, blk, 0, s, x, gamma, beta, y, mean, rstd, rows, eps, slope); break;
-        default: hipLaunchKernelGGL(ln_lrelu_fwd_kernel<4>, grid, blk, 0, s, x, gamma, beta, y, mean, rstd, rows, eps, slope); break;
+        case 1: hipLaunchKernelGGL((ln_lrelu_fwd_kernel<1, IO>), grid, blk, 0, s, xi, gamma, beta, yo, mean, rstd, rows, eps, slope); break;
+        case 2: hipLaunchKernelGGL((ln_lrelu_fwd_kernel<2, IO>), grid, blk, 0, s, xi, gamma, beta, yo, mean, rstd, rows, eps, slope); break;
+        case 3: hipLaunchKernelGGL((ln_lrelu_fwd_kernel<3, IO>), grid, blk, 0, s, xi, gamma, beta, yo, mean, rstd, rows, eps, slope); break;
+        default: hipLaunchKernelGGL((ln_lrelu_fwd_kernel<4, IO>), grid, blk, 0, s, xi, gamma, beta, yo, mean, rstd, rows, eps, slope); break;
     }
     return (int)hipGetLastError();
+}
+
+template <typename IO>
+int ln_backward(const void *grad_y, const void *x, const void *y, const float *gamma, const float *mean, const float *rstd, void *grad_x,
+                float *grad_gamma, float *grad_beta, void *scratch, long rows, int D, float slope, hipStream_t s)
+{
+    if (D <= 0 || D % 256 != 0 || D > 1024) return DDSP_ERANGE;
+    if (rows == 0) {   // an empty shard (batch < world size): no rows contribute, the parameter gradients are zero
+        if (!grad_gamma || !grad_beta) return DDSP_EINVAL;
+        hipError_t e = hipMemsetAsync(grad_gamma, 0, sizeof(float) * (size_t)D, s);
+        if (e == hipSuccess) e = hipMemsetAsync(grad_beta, 0, sizeof(float) * (size_t)D, s);
+        return (int)e;
+    }
+    if (!grad_y || !x || !y || !gamma || !mean || !rstd || !grad_x || !grad_gamma || !grad_beta || !scratch || rows < 0) return DDSP_EINVAL;
+    typedef typename IO::T T;
+    const T *gy = (const T *)grad_y, *xi = (const T *)x, *yi = (const T *)y;
+    T *gx = (T *)grad_x;
+    const long want = (rows + 3) / 4;
+    const int blocks = (int)(want < kLnBlocks ? want : kLnBlocks);
+    const dim3 grid((unsigned)blocks), blk(256);
+    float *part = (float *)scratch;
+    switch (D / 256) {
+        case 1: hipLaunchKernelGGL((ln_lrelu_bwd_kernel<1, IO>), grid, blk, 0, s, gy, xi, yi, gamma, mean, rstd, gx, part, rows, slope); break;
+        case 2: hipLaunchKernelGGL((ln_lrelu_bwd_kernel<2, IO>), grid, blk, 0, s, gy, xi, yi, gamma, mean, rstd, gx, part, rows, slope); break;
+        case 3: hipLaunchKernelGGL((ln_lrelu_bwd_kernel<3, IO>), grid, blk, 0, s, gy, xi, yi, gamma, mean, rstd, gx, part, rows, slope); break;
+        default: hipLaunchKernelGGL((ln_lrelu_bwd_kernel<4, IO>), grid, blk, 0, s, gy, xi, yi, gamma, mean, rstd, gx, part, rows, slope); break;
+    }
+    hipLaunchKernelGGL(ln_lrelu_finish_kernel, dim3((unsigned)(2 * D / 64)), dim3(1024), 0, s, part, blocks, D, grad_gamma, grad_beta);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int ddsp_ln_lrelu_forward(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd,
+                                     long rows, int D, float eps, float slope, void *stream)
+{
+    return ln_forward<IoF32>(x, gamma, beta, y, mean, rstd, rows, D, eps, slope, (hipStream_t)stream);
 }
 
 extern "C" int ddsp_ln_lrelu_backward(const float *grad_y, const float *x, const float *y, const float *gamma, const float *mean,
                                       const float *rstd, float *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
                                       long rows, int D, float slope, void *stream)
 {
-    if (D <= 0 || D % 256 != 0 || D > 1024) return DDSP_ERANGE;
-    if (rows == 0) {   // an empty shard (batch < world size): no rows contribute, the parameter gradients are zero
-        if (!grad_gamma || !grad_beta) return DDSP_EINVAL;
-        hipError_t e = hipMemsetAsync(grad_gamma, 0, sizeof(float) * (size_t)D, (hipStream_t)stream);
-        if (e == hipSuccess) e = hipMemsetAsync(grad_beta, 0, sizeof(float) * (size_t)D, (hipStream_t)stream);
-        return (int)e;
-    }
-    if (!grad_y || !x || !y || !gamma || !mean || !rstd || !grad_x || !grad_gamma || !grad_beta || !scratch || rows < 0) return DDSP_EINVAL;
-    const long want = (rows + 3) / 4;
-    const int blocks = (int)(want < kLnBlocks ? want : kLnBlocks);
-    const dim3 grid((unsigned)blocks), blk(256);
+    return ln_backward<IoF32>(grad_y, x, y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, scratch, rows, D, slope, (hipStream_t)stream);
+}
+
+extern "C" int ddsp_ln_lrelu_forward_16(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd,
+                                        long rows, int D, float eps, float slope, int io_type, void *stream)
+{
+    if (io_type == DDSP_IO_BF16) return ln_forward<IoBf16>(x, gamma, beta, y, mean, rstd, rows, D, eps, slope, (hipStream_t)stream);
+    if (io_type == DDSP_IO_F16) return ln_forward<IoF16>(x, gamma, beta, y, mean, rstd, rows, D, eps, slope, (hipStream_t)stream);
+    return DDSP_EINVAL;
+}
+
+extern "C" int ddsp_ln_lrelu_backward_16(const void *grad_y, const void *x, const void *y, const float *gamma, const float *mean,
+                                         const float *rstd, void *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
+                                         long rows, int D, float slope, int io_type, void *stream)
+{
     hipStream_t s = (hipStream_t)stream;
-    float *part = (float *)scratch;
-    switch (D / 256) {
-        case 1: hipLaunchKernelGGL(ln_lrelu_bwd_kernel<1>, grid, blk, 0, s, grad_y, x, y, gamma, mean, rstd, grad_x, part, rows, slope); break;
-        case 2: hipLaunchKernelGGL(ln_lrelu_bwd_kernel<2>, grid, blk, 0, s, grad_y, x, y, gamma, mean, rstd, grad_x, part, rows, slope); break;
-        case 3: hipLaunchKernelGGL(ln_lrelu_bwd_kernel<3>, grid, blk, 0, s, grad_y, x, y, gamma, mean, rstd, grad_x, part, rows, slope); break;
-        default: hipLaunchKernelGGL(ln_lrelu_bwd_kernel<4>, grid, blk, 0, s, grad_y, x, y, gamma, mean, rstd, grad_x, part, rows, slope); break;
-    }
-    hipLaunchKernelGGL(ln_lrelu_finish_kernel, dim3((unsigned)(2 * D / 64)), dim3(1024), 0, s, part, blocks, D, grad_gamma, grad_beta);
-    return (int)hipGetLastError();
+    if (io_type == DDSP_IO_BF16) return ln_backward<IoBf16>(grad_y, x, y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, scratch, rows, D, slope, s);
+    if (io_type == DDSP_IO_F16) return ln_backward<IoF16>(grad_y, x, y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, scratch, rows, D, slope, s);
+    return DDSP_EINVAL;
 }

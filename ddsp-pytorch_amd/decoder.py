@@ -31,24 +31,36 @@ def _dense_stack(n_in: int, width: int, depth: int) -> nn.Module:
 
 
 class _LayerNormLeakyReLU(torch.autograd.Function):
-    """LayerNorm -> LeakyReLU of one MLP block as one HIP pass each way (include/ddsp_hip.h: ddsp_ln_lrelu_*)."""
+    """LayerNorm -> LeakyReLU of one MLP block as one HIP pass each way (include/ddsp_hip.h: ddsp_ln_lrelu_*).
+    fp32 activations take the fp32 entry points; bf16 / fp16 activations (torch.autocast: the Linear in front produced them
+    and the Linear behind wants them) are read and written as such by the `_16` entry points -- no cast pass either side;
+    statistics, gamma / beta and their gradients are fp32 in both cases."""
+
+    _IO = {torch.bfloat16: 1, torch.float16: 2}
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, gamma, beta, eps, slope):
         x = x.contiguous()
         D = x.shape[-1]
         rows = x.numel() // D
-        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        g, b = gamma.detach().contiguous().float(), beta.detach().contiguous().float()
         y = torch.empty_like(x)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
+        L = _lib.lib()
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().ddsp_ln_lrelu_forward(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(),
-                                                        rstd.data_ptr(), rows, D, float(eps), float(slope),
-                                                        torch.cuda.current_stream().cuda_stream), "ddsp_ln_lrelu_forward")
+            stream = torch.cuda.current_stream().cuda_stream
+            if x.dtype == torch.float32:
+                rc = L.ddsp_ln_lrelu_forward(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                             rows, D, float(eps), float(slope), stream)
+            else:
+                rc = L.ddsp_ln_lrelu_forward_16(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                rows, D, float(eps), float(slope), _LayerNormLeakyReLU._IO[x.dtype], stream)
+        _lib.check(rc, "ddsp_ln_lrelu_forward")
         ctx.save_for_backward(x, y, g, mean, rstd)
         ctx.slope = float(slope)
+        ctx.param_dtypes = (gamma.dtype, beta.dtype)
         return y
 
     @staticmethod
@@ -57,20 +69,26 @@ class _LayerNormLeakyReLU(torch.autograd.Function):
         x, y, g, mean, rstd = ctx.saved_tensors
         D = x.shape[-1]
         rows = x.numel() // D
-        gy = gy.contiguous()
+        gy = gy.contiguous().to(x.dtype)
         gx = torch.empty_like(x)
         dg, db = torch.empty_like(g), torch.empty_like(g)
         L = _lib.lib()
         scratch = torch.empty(L.ddsp_ln_lrelu_scratch_bytes(D), device=x.device, dtype=torch.uint8)
         with torch.cuda.device(x.device):
-            _lib.check(L.ddsp_ln_lrelu_backward(gy.data_ptr(), x.data_ptr(), y.data_ptr(), g.data_ptr(), mean.data_ptr(),
-                                                rstd.data_ptr(), gx.data_ptr(), dg.data_ptr(), db.data_ptr(), scratch.data_ptr(),
-                                                rows, D, ctx.slope, torch.cuda.current_stream().cuda_stream), "ddsp_ln_lrelu_backward")
-        return gx, dg, db, None, None
+            stream = torch.cuda.current_stream().cuda_stream
+            if x.dtype == torch.float32:
+                rc = L.ddsp_ln_lrelu_backward(gy.data_ptr(), x.data_ptr(), y.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                              gx.data_ptr(), dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), rows, D, ctx.slope, stream)
+            else:
+                rc = L.ddsp_ln_lrelu_backward_16(gy.data_ptr(), x.data_ptr(), y.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                 gx.data_ptr(), dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), rows, D, ctx.slope,
+                                                 _LayerNormLeakyReLU._IO[x.dtype], stream)
+        _lib.check(rc, "ddsp_ln_lrelu_backward")
+        return gx, dg.to(ctx.param_dtypes[0]), db.to(ctx.param_dtypes[1]), None, None
 
 
-# Under torch.autocast the Linear layers hand over bf16 / fp16 activations; the fused passes take them (their
-# `custom_fwd(cast_inputs=float32)` converts) and return fp32, so only the GEMMs run in the low-precision type.
+# Under torch.autocast the Linear layers hand over bf16 / fp16 activations: the fused LayerNorm pass reads and writes
+# them as they are; the head non-linearity converts (`custom_fwd(cast_inputs=float32)`) and returns fp32.
 _FUSED_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
 
 

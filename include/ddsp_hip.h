@@ -216,6 +216,17 @@ int ddsp_ln_lrelu_forward(const float *x, const float *gamma, const float *beta,
 int ddsp_ln_lrelu_backward(const float *grad_y, const float *x, const float *y, const float *gamma, const float *mean,
                            const float *rstd, float *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
                            long rows, int D, float slope, void *stream);
+/* The same passes on 16-bit activations (io_type: DDSP_IO_BF16 / DDSP_IO_F16) for torch.autocast callers: x, y and their
+ * gradients are bf16 / fp16 arrays (read and written as such: no cast pass on either side), gamma / beta, the row
+ * statistics, the parameter gradients and all arithmetic stay fp32.  Reference: train/train.py:50 (`precision=16`). */
+#define DDSP_IO_BF16 1
+#define DDSP_IO_F16 2
+int ddsp_ln_lrelu_forward_16(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd,
+                             long rows, int D, float eps, float slope, int io_type, void *stream);
+int ddsp_ln_lrelu_backward_16(const void *grad_y, const void *x, const void *y, const float *gamma, const float *mean,
+                              const float *rstd, void *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
+                              long rows, int D, float slope, int io_type, void *stream);
+
 
 #ifdef __cplusplus
 }

@@ -434,3 +434,36 @@ def test_train_step_fp16_with_grad_scaler_survives_overflow():
     for _ in range(12):
         loss, _ = ddsp.train_step(model, loss_fn, opt, batch, amp_dtype=torch.float16, scaler=scaler)
     assert np.isfinite(float(loss)) and all(bool(torch.isfinite(v).all()) for v in model.state_dict().values())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_layernorm_16bit_activations_equal_fp32_pass_up_to_rounding(dtype):
+    """Under autocast the fused LayerNorm + LeakyReLU pass reads and writes bf16 / fp16 activations directly
+    (`ddsp_ln_lrelu_*_16`): same fp32 arithmetic inside, so it must equal the fp32 pass on the same (already rounded) inputs
+    up to ONE rounding of its outputs to the 16-bit type; parameter gradients stay fp32."""
+    from ddsp_pytorch_amd.decoder import _LayerNormLeakyReLU
+    torch.manual_seed(12)
+    rows, D = 300, 512
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    x16 = torch.randn(3, rows // 3, D, device="cuda").to(dtype)
+    gy16 = torch.randn(3, rows // 3, D, device="cuda").to(dtype)
+    gamma = (1.0 + 0.3 * torch.randn(D, device="cuda")).requires_grad_()
+    beta = (0.2 * torch.randn(D, device="cuda")).requires_grad_()
+
+    def run(x, gy):
+        for p in (gamma, beta):
+            p.grad = None
+        x = x.clone().requires_grad_()
+        y = _LayerNormLeakyReLU.apply(x, gamma, beta, 1e-5, 0.01)
+        y.backward(gy)
+        return y.detach(), x.grad, gamma.grad.clone(), beta.grad.clone()
+
+    y32, gx32, dg32, db32 = run(x16.float(), gy16.float())
+    y16, gx16, dg16, db16 = run(x16, gy16)
+    assert y16.dtype == dtype and gx16.dtype == dtype and dg16.dtype == torch.float32 and db16.dtype == torch.float32
+    assert float((y16.float() - y32).abs().max()) <= ulp * float(y32.abs().max())
+    assert float((gx16.float() - gx32).abs().max()) <= 2 * ulp * float(gx32.abs().max())
+    # the 16-bit pass sees y rounded to 16 bits only for the sign of the activation: the parameter gradients are the same sums
+    assert float((dg16 - dg32).abs().max()) <= 1e-4 * float(dg32.abs().max())
+    assert float((db16 - db32).abs().max()) <= 1e-4 * float(db32.abs().max())
