@@ -235,3 +235,19 @@ def test_cfg5_per_gpu_train_step_full_shape():
         assert nbytes == 4 * sum(p.numel() for p in params) and np.isfinite(float(l0)) and np.isfinite(float(l1))
     finally:
         gru_mod.set_debug(old)
+
+
+def test_graphed_synth_hop512_uses_the_fft_noise_form():
+    """hipGraph capture of harmonics + noise at the 48 kHz shape (hop 512, 257 bands): the noise runs in the in-LDS FFT form
+    with the Philox offset read from the device counter at replay time -- replays equal the eager calls, draw after draw."""
+    class Conf:
+        n_harmonics, sample_rate, hop_length = 200, 48000, 512
+
+    shape = syn.SynthShape("g512", 2, 48000, 512, 9, 200, 257)          # 18 frames: nine frame pairs
+    _, x = controls(shape, 23)
+    gs = ddsp.GraphedSynth(Conf, 2, 9, 257, noise_seed=4)
+    per_call = 2 * 9 * (512 // 4)
+    for call in range(3):
+        eager, _, _ = ddsp.osc_forward(x["f0"], x["c"], x["a"], 512, 48000)
+        ddsp.noise_forward(x["H"], 512, seed=4, offset=call * per_call, out=eager, accumulate=True)
+        assert torch.equal(gs(x), eager), call
