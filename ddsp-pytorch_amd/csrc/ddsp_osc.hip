@@ -270,7 +270,8 @@ __global__ void __launch_bounds__(256) osc_totals_kernel(OscParams p)
 {
     extern __shared__ double tot_s[];  // [FPB][H]
     const int G = 1 << p.logG, FPB = 256 >> p.logG;
-    const int b = blockIdx.x / p.NSB, sb = blockIdx.x - b * p.NSB;
+    const int blk = (int)xcd_block(blockIdx.x, gridDim.x);
+    const int b = blk / p.NSB, sb = blk - b * p.NSB;
     const int fl = threadIdx.x >> p.logG, j = threadIdx.x & (G - 1);
     int t = sb * FPB + fl;
     const bool active = t < p.T;
@@ -398,7 +399,7 @@ __global__ void __launch_bounds__(256, (SKIP && K <= 13) ? 3 : 1) osc_synth_kern
     if (VARIANT == VAR_EXACT && !p.force_exact && *p.redo_flag == 0) return;
     if (VARIANT == VAR_FAST && POW2 && p.R >= 8 && (p.redo_flag[1] != 0) != SKIP) return;
     const int G = 1 << p.logG;
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long gid = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     const int j = threadIdx.x & (G - 1);
     long f = gid >> p.logG;
     const long nframes = (long)p.B * p.T;

@@ -130,13 +130,14 @@ __global__ void __launch_bounds__(256) osc_bwd_kernel(OscParams p, int use_lds)
 {
     extern __shared__ float g_s[];  // [FPB][R] tile of grad_y (when it fits)
     const int G = 1 << p.logG, FPB = 256 >> p.logG;
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned blk = xcd_block(blockIdx.x, gridDim.x);
+    const long gid = (long)blk * 256 + threadIdx.x;
     const int j = threadIdx.x & (G - 1), fl = threadIdx.x >> p.logG;
     long f = gid >> p.logG;
     const long nframes = (long)p.B * p.T;
     const bool active = f < nframes;
     if (use_lds) {
-        const long f0 = (long)blockIdx.x * FPB;
+        const long f0 = (long)blk * FPB;
         const long total = min((long)FPB, nframes - f0) * p.R;
         for (long e = threadIdx.x; e < total; e += 256) g_s[e] = p.grad_y[f0 * p.R + e];
         __syncthreads();

@@ -39,6 +39,16 @@ struct OscParams {
     float sr;         // float(sample_rate)
 };
 
+// XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx b and b + 8 share an L2, observed
+// behaviour: speed only).  Consecutive *logical* blocks cover consecutive frames of one batch row and share halo rows of
+// the frame-rate scratch, so logical blocks [i * n/8, (i + 1) * n/8) are handed to the hardware blocks of one XCD.
+__device__ __forceinline__ unsigned xcd_block(unsigned bid, unsigned nblocks)
+{
+    const unsigned per = nblocks >> 3;
+    if (per == 0 || bid >= (per << 3)) return bid;          // the ragged tail keeps its position
+    return (bid & 7u) * per + (bid >> 3);
+}
+
 // ---- cross-lane helpers -------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
