@@ -73,6 +73,10 @@ def lib():
     L.ddsp_gru_forward.argtypes = [vp] * 9 + [i32] * 3 + [vp]
     L.ddsp_gru_backward.restype = i32
     L.ddsp_gru_backward.argtypes = [vp] * 11 + [i32] * 3 + [vp]
+    L.ddsp_gru_forward_bf16.restype = i32
+    L.ddsp_gru_forward_bf16.argtypes = [vp] * 9 + [i32] * 3 + [vp]
+    L.ddsp_gru_backward_bf16.restype = i32
+    L.ddsp_gru_backward_bf16.argtypes = [vp] * 11 + [i32] * 3 + [vp]
     L.ddsp_gru_set_mode.restype = i32
     L.ddsp_gru_set_mode.argtypes = [i32]
     L.ddsp_gru_set_fault_step.restype = i32
@@ -118,7 +122,7 @@ def lib():
 EXPORTS = ("ddsp_hip_abi_version", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_noise_forward", "ddsp_noise_forward_counter",
            "ddsp_osc_backward_scratch_bytes", "ddsp_osc_backward", "ddsp_noise_backward",
            "ddsp_osc_set_tiling", "ddsp_noise_set_generic", "ddsp_profile_enable", "ddsp_profile_read",
-           "ddsp_gru_scratch_bytes", "ddsp_gru_max_batch", "ddsp_gru_forward", "ddsp_gru_backward", "ddsp_gru_status", "ddsp_gru_set_mode", "ddsp_gru_set_fault_step",
+           "ddsp_gru_scratch_bytes", "ddsp_gru_max_batch", "ddsp_gru_forward", "ddsp_gru_backward", "ddsp_gru_forward_bf16", "ddsp_gru_backward_bf16", "ddsp_gru_status", "ddsp_gru_set_mode", "ddsp_gru_set_fault_step",
            "ddsp_spectral_loss_scratch_bytes", "ddsp_spectral_loss", "ddsp_scaled_sigmoid_forward", "ddsp_scaled_sigmoid_backward",
            "ddsp_ln_lrelu_scratch_bytes", "ddsp_ln_lrelu_forward", "ddsp_ln_lrelu_backward", "ddsp_ln_lrelu_forward_16", "ddsp_ln_lrelu_backward_16",
            "ddsp_reverb_impulse", "ddsp_reverb_impulse_backward", "ddsp_spectral_mul", "ddsp_spectral_mul_backward",

@@ -65,6 +65,7 @@ struct GruParams {
     gu32 *status;         // 0 ok / GRU_TIMEOUT
     int B, T, Hd;
     int NG, NGpad, NW, BL;  // groups, padded group count (blockIdx modulus), workgroups per group, rows per group
+    int lowp;             // 1: the products run on the matrix cores in bf16 (autocast callers), fp32 accumulate
     long spin_ticks;      // bound of every spin, in ticks of the 100 MHz wall clock
     int fault_step;       // test hook (ddsp_gru_set_mode(2)): workgroup 0 withholds its publishes from this step on; -1 = off
 };
@@ -84,8 +85,9 @@ __device__ __forceinline__ unsigned long long pack_granule(unsigned epoch, float
 // timeout / abort.
 template <int RB, bool FIRST_LIGHT>
 __device__ __forceinline__ bool sweep_rows(gu64 *src, float *dst, int rows, int Hd, int HP, unsigned epoch, gu32 *status, int NT,
-                                           long spin_ticks)
+                                           long spin_ticks, int DS = 0)
 {
+    if (DS == 0) DS = HP;                                 // destination row stride in LDS (the granule rows are HP apart)
     const long t0 = wall_clock64();
     const int kc[2] = {(int)threadIdx.x, (int)threadIdx.x + NT};
     const int nb = (rows + RB - 1) / RB;                  // <= 16 batches
@@ -133,7 +135,7 @@ __device__ __forceinline__ bool sweep_rows(gu64 *src, float *dst, int rows, int 
                     if (row < rows) {
 #pragma unroll
                         for (int c = 0; c < 2; ++c)
-                            if (kc[c] < Hd) dst[row * HP + kc[c]] = __uint_as_float((unsigned)x[r][c]);
+                            if (kc[c] < Hd) dst[row * DS + kc[c]] = __uint_as_float((unsigned)x[r][c]);
                     }
                 }
             }
@@ -483,6 +485,321 @@ __global__ void __launch_bounds__(256 * NRS, 1) gru_bwd_kernel(GruParams p)
     }
 }
 
+// ---- bf16 matrix-core variants (torch.autocast callers: train/train.py:50 `precision=16`) -----------------------------
+// Same decomposition, hand-off protocol, gate arithmetic (fp32) and failure handling as above; only the products
+// h_{t-1} W^T (forward) and (dr, dz, dhn) W (backward) change: `v_mfma_f32_16x16x32_bf16`, fp32 accumulation, weights held
+// as bf16 B-operand fragments in registers for the whole sequence, the group's rows (<= 16) as the A operand converted from
+// the fp32 LDS image on the fly.  The K range is dealt over the workgroup's four wavefronts (one per SIMD), their partial
+// tiles meet in LDS, and thread (row, unit) = (tid / 16, tid % 16) does the gate math.  A step's arithmetic drops from
+// ~1.5 us of VALU work to a dozen MFMAs per wavefront, so the step is left with its hand-off latency.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8_t to_bf16x8(float4 a, float4 b)
+{
+    bf16x8_t r;
+    r[0] = (__bf16)a.x; r[1] = (__bf16)a.y; r[2] = (__bf16)a.z; r[3] = (__bf16)a.w;
+    r[4] = (__bf16)b.x; r[5] = (__bf16)b.y; r[6] = (__bf16)b.z; r[7] = (__bf16)b.w;
+    return r;
+}
+
+constexpr int kMfmaRows = 16;     // rows of one MFMA tile = the most batch rows a group may hold in these variants
+
+template <int KP>
+__global__ void __launch_bounds__(256, 1) gru_fwd_mfma_kernel(GruParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float h_s[];   // [16][HS] h_{t-1} | red [4][3][16][16] | failure flag
+    constexpr int HP = 16 * KP, HS = HP + 4, NKS = HP / 32, KSW = (NKS + 3) / 4;
+    float *red = h_s + kMfmaRows * HS;
+    int *fail_s = reinterpret_cast<int *>(red + 4 * 3 * 256);
+    const int group = blockIdx.x % p.NGpad, member = blockIdx.x / p.NGpad;
+    if (group >= p.NG) return;
+    const int row0 = group * p.BL;
+    const int nrows = min(p.BL, p.B - row0);
+    if (nrows <= 0) return;
+    const int Hd = p.Hd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ln = lane & 15, kb = lane >> 4;
+    const size_t G3 = (size_t)3 * Hd;
+
+    // B fragments: B[k = 32 s + 8 kb + i][col ln] = W_hh[g][unit member*16 + ln][k], k-steps s = wave + 4 si
+    bf16x8_t wb[3][KSW];
+    {
+        const int u = member * kUnits + ln;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int si = 0; si < KSW; ++si) {
+                const int s = wave + 4 * si;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k = 32 * s + 8 * kb + i;
+                    const float v = (s < NKS && u < Hd && k < Hd) ? p.w_hh[((size_t)g * Hd + u) * Hd + k] : 0.0f;
+                    wb[g][si][i] = (__bf16)v;
+                }
+            }
+    }
+    // gate thread (row gr, unit gu) of this workgroup
+    const int gr = threadIdx.x >> 4, gul = threadIdx.x & 15;
+    const int gu = member * kUnits + gul;
+    const bool gate = gr < nrows && gu < Hd;
+    float bh[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bh[g] = (gate && p.b_hh) ? p.b_hh[g * Hd + gu] : 0.0f;
+
+    for (int i = threadIdx.x; i < kMfmaRows * HS; i += 256) {
+        const int bl = i / HS, k = i - bl * HS;
+        h_s[i] = (bl < nrows && k < Hd && p.h0) ? p.h0[(size_t)(row0 + bl) * Hd + k] : 0.0f;
+    }
+    if (threadIdx.x == 0) *fail_s = 0;
+    __syncthreads();
+
+    gu64 *xg = p.xchg + (size_t)group * 2 * p.BL * HP;  // [2][BL][HP]
+    float pre[3] = {0.0f, 0.0f, 0.0f};
+    if (gate) {
+        const size_t bt = (size_t)(row0 + gr) * p.T;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) pre[g] = p.gi[bt * G3 + g * Hd + gu];
+    }
+    const int fault_from = (p.fault_step >= 0 && blockIdx.x == 0) ? p.fault_step : 0x7fffffff;
+    int t_reached = 0;
+    for (int t = 0; t < p.T; ++t) {
+        if (t > 0) {
+            const bool ok = sweep_rows<4, false>(xg + (size_t)((t - 1) & 1) * p.BL * HP, h_s, nrows, Hd, HP, (unsigned)t, p.status, 256,
+                                                 p.spin_ticks, HS);
+            if (!ok && (threadIdx.x & 63) == 0) *fail_s = 1;
+        }
+        __syncthreads();
+        if (*fail_s) break;
+        t_reached = t + 1;
+        const float hp = gate ? h_s[gr * HS + gu] : 0.0f;
+        const float gir = pre[0], giz = pre[1], gin = pre[2];
+        if (gate && t + 1 < p.T) {
+            const size_t bt1 = (size_t)(row0 + gr) * p.T + t + 1;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) pre[g] = p.gi[bt1 * G3 + g * Hd + gu];
+        }
+        f32x4_t acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int si = 0; si < KSW; ++si) {
+            const int s = wave + 4 * si;
+            if (s < NKS) {   // wave-uniform
+                float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0;
+                if (ln < nrows) {
+                    a0 = *reinterpret_cast<const float4 *>(h_s + ln * HS + 32 * s + 8 * kb);
+                    a1 = *reinterpret_cast<const float4 *>(h_s + ln * HS + 32 * s + 8 * kb + 4);
+                }
+                const bf16x8_t a = to_bf16x8(a0, a1);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wb[g][si], acc[g], 0, 0, 0);
+            }
+        }
+        // D: row 4 kb + i, col ln
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[((wave * 3 + g) * 16 + 4 * kb + i) * 16 + ln] = acc[g][i];
+        __syncthreads();
+        if (gate) {
+            float sg[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                sg[g] = (red[((0 * 3 + g) * 16 + gr) * 16 + gul] + red[((1 * 3 + g) * 16 + gr) * 16 + gul]) +
+                        (red[((2 * 3 + g) * 16 + gr) * 16 + gul] + red[((3 * 3 + g) * 16 + gr) * 16 + gul]);
+            const size_t bt = (size_t)(row0 + gr) * p.T + t;
+            const float ghn = sg[2] + bh[2];
+            const float r = sigmoidf_(gir + (sg[0] + bh[0]));
+            const float z = sigmoidf_(giz + (sg[1] + bh[1]));
+            const float n = tanhf_(__fmaf_rn(r, ghn, gin));
+            const float hnew = __fmaf_rn(hp - n, z, n);
+            if (t < fault_from) publish(xg + ((size_t)(t & 1) * p.BL + gr) * HP + gu, (unsigned)t + 1u, hnew);
+            p.y[bt * Hd + gu] = hnew;
+            if (p.gates) {
+                p.gates[bt * G3 + gu] = r;
+                p.gates[bt * G3 + Hd + gu] = z;
+                p.gates[bt * G3 + 2 * Hd + gu] = n;
+            }
+            if (p.hn) p.hn[bt * Hd + gu] = ghn;
+            if (t == p.T - 1) p.hT[(size_t)(row0 + gr) * Hd + gu] = hnew;
+        }
+        // (no barrier here: the next sweep rewrites h_s, which nobody reads any more in this step, and `red` is only rewritten
+        //  behind the next step's first barrier, which the gate threads reach after their reads)
+    }
+    __syncthreads();
+    if (*fail_s) {
+        if (threadIdx.x == 0) __hip_atomic_store(p.status, (unsigned)GRU_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float nan = __builtin_nanf("");
+        if (gate) {
+            p.hT[(size_t)(row0 + gr) * Hd + gu] = nan;
+            for (int t = t_reached; t < p.T; ++t) {
+                const size_t bt = (size_t)(row0 + gr) * p.T + t;
+                p.y[bt * Hd + gu] = nan;
+                if (p.gates) {
+                    p.gates[bt * G3 + gu] = nan;
+                    p.gates[bt * G3 + Hd + gu] = nan;
+                    p.gates[bt * G3 + 2 * Hd + gu] = nan;
+                }
+                if (p.hn) p.hn[bt * Hd + gu] = nan;
+            }
+        }
+    }
+}
+
+template <int KP>
+__global__ void __launch_bounds__(256, 1) gru_bwd_mfma_kernel(GruParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float d_s[];   // [16][3][HS] gate gradients | red [4][16][16] | failure flag
+    constexpr int HP = 16 * KP, HS = HP + 4, NKS = 3 * HP / 32, KSW = (NKS + 3) / 4;
+    float *red = d_s + kMfmaRows * 3 * HS;
+    int *fail_s = reinterpret_cast<int *>(red + 4 * 256);
+    const int group = blockIdx.x % p.NGpad, member = blockIdx.x / p.NGpad;
+    if (group >= p.NG) return;
+    const int row0 = group * p.BL;
+    const int nrows = min(p.BL, p.B - row0);
+    if (nrows <= 0) return;
+    const int Hd = p.Hd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ln = lane & 15, kb = lane >> 4;
+    const size_t G3 = (size_t)3 * Hd;
+
+    // B fragments over the K axis (gate g, source unit u'): k-step s = wave + 4 si covers g = s / (HP/32), u' = 32 (s % (HP/32)) + 8 kb + i;
+    // B[k][col ln] = W_hh[g][u'][column member*16 + ln]
+    bf16x8_t wb[KSW];
+    {
+        const int kcol = member * kUnits + ln;
+#pragma unroll
+        for (int si = 0; si < KSW; ++si) {
+            const int s = wave + 4 * si;
+            const int g = s / (HP / 32), sb = s - g * (HP / 32);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int uu = 32 * sb + 8 * kb + i;
+                const float v = (s < NKS && kcol < Hd && uu < Hd) ? p.w_hh[((size_t)g * Hd + uu) * Hd + kcol] : 0.0f;
+                wb[si][i] = (__bf16)v;
+            }
+        }
+    }
+    for (int i = threadIdx.x; i < kMfmaRows * 3 * HS; i += 256) d_s[i] = 0.0f;
+    for (int i = threadIdx.x; i < 4 * 256; i += 256) red[i] = 0.0f;
+    if (threadIdx.x == 0) *fail_s = 0;
+    __syncthreads();
+
+    gu64 *xg = p.xchg + (size_t)group * 2 * p.BL * 3 * HP;  // [2][BL][3][HP]
+    // gate thread (row gr, column gk)
+    const int gr = threadIdx.x >> 4, gkl = threadIdx.x & 15;
+    const int gk = member * kUnits + gkl;
+    const bool gate = gr < nrows && gk < Hd;
+    float carry = (gate && p.dhT) ? p.dhT[(size_t)(row0 + gr) * Hd + gk] : 0.0f;
+    float direct = 0.0f;
+    float dyv = 0.0f, f_r = 0.0f, f_z = 0.0f, f_hn = 0.0f, f_n = 0.0f, f_dir = 0.0f;
+    float raw[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    auto fetch = [&](int t) {
+        if (gate) {
+            const size_t bt = (size_t)(row0 + gr) * p.T + t;
+            raw[0] = p.gates[bt * G3 + gk];
+            raw[1] = p.gates[bt * G3 + Hd + gk];
+            raw[2] = p.gates[bt * G3 + 2 * Hd + gk];
+            raw[3] = p.hn[bt * Hd + gk];
+            raw[4] = (t > 0) ? p.y[(bt - 1) * Hd + gk] : (p.h0 ? p.h0[(size_t)(row0 + gr) * Hd + gk] : 0.0f);
+            raw[5] = p.dy[bt * Hd + gk];
+        }
+    };
+    auto derive = [&]() {
+        const float r = raw[0], z = raw[1], n = raw[2], ghn = raw[3], hp = raw[4];
+        dyv = raw[5];
+        f_n = (1.0f - z) * (1.0f - n * n);
+        f_r = (f_n * ghn) * (r * (1.0f - r));
+        f_z = (hp - n) * (z * (1.0f - z));
+        f_hn = f_n * r;
+        f_dir = z;
+    };
+    fetch(p.T - 1);
+    derive();
+    if (p.T > 1) fetch(p.T - 2);
+
+    const int fault_from = (p.fault_step >= 0 && blockIdx.x == 0) ? p.fault_step : 0x7fffffff;
+    int s_reached = 0;
+    for (int s = 0; s < p.T; ++s) {
+        const int t = p.T - 1 - s;
+        const unsigned epoch = (unsigned)s + 1u;
+        gu64 *slot = xg + (size_t)(s & 1) * p.BL * 3 * HP;
+        // 1. dh of this step = dy + (what the previous step's product left in `red`) ; gate gradients; publish
+        if (gate) {
+            if (s > 0)
+                carry = direct + ((red[(0 * 16 + gr) * 16 + gkl] + red[(1 * 16 + gr) * 16 + gkl]) +
+                                  (red[(2 * 16 + gr) * 16 + gkl] + red[(3 * 16 + gr) * 16 + gkl]));
+            const size_t bt = (size_t)(row0 + gr) * p.T + t;
+            const float dh = dyv + carry;
+            const float dr_pre = dh * f_r, dz_pre = dh * f_z, dhn = dh * f_hn, dn_pre = dh * f_n;
+            direct = dh * f_dir;
+            gu64 *gdst = slot + (size_t)gr * 3 * HP + gk;
+            if (s < fault_from) {
+                publish(gdst, epoch, dr_pre);
+                publish(gdst + HP, epoch, dz_pre);
+                publish(gdst + 2 * HP, epoch, dhn);
+            }
+            p.d_gi[bt * G3 + gk] = dr_pre;
+            p.d_gi[bt * G3 + Hd + gk] = dz_pre;
+            p.d_gi[bt * G3 + 2 * Hd + gk] = dn_pre;
+            p.d_gh[bt * G3 + gk] = dr_pre;
+            p.d_gh[bt * G3 + Hd + gk] = dz_pre;
+            p.d_gh[bt * G3 + 2 * Hd + gk] = dhn;
+        }
+        s_reached = s + 1;
+        // 2. the group's gate gradients -> LDS (3 * nrows rows of width Hd)
+        {
+            const bool ok = sweep_rows<12, true>(slot, d_s, 3 * nrows, Hd, HP, epoch, p.status, 256, p.spin_ticks, HS);
+            if (!ok && (threadIdx.x & 63) == 0) *fail_s = 1;
+        }
+        __syncthreads();
+        if (*fail_s) break;
+        derive();
+        if (t > 1) fetch(t - 2);
+        // 3. partial tiles of dh_{t-1} = sum over (gate, source unit)
+        f32x4_t acc = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int si = 0; si < KSW; ++si) {
+            const int ks = wave + 4 * si;
+            if (ks < NKS) {   // wave-uniform
+                const int g = ks / (HP / 32), sb = ks - g * (HP / 32);
+                float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0;
+                if (ln < nrows) {
+                    const float *src = d_s + (ln * 3 + g) * HS + 32 * sb + 8 * kb;
+                    a0 = *reinterpret_cast<const float4 *>(src);
+                    a1 = *reinterpret_cast<const float4 *>(src + 4);
+                }
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(to_bf16x8(a0, a1), wb[si], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[(wave * 16 + 4 * kb + i) * 16 + ln] = acc[i];
+        __syncthreads();   // `red` complete (read at the top of the next step); d_s free for the next sweep
+    }
+    if (*fail_s) {
+        if (threadIdx.x == 0) __hip_atomic_store(p.status, (unsigned)GRU_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float nan = __builtin_nanf("");
+        if (gate) {
+            p.dh0[(size_t)(row0 + gr) * Hd + gk] = nan;
+            for (int s = s_reached; s < p.T; ++s) {
+                const size_t bt = (size_t)(row0 + gr) * p.T + (p.T - 1 - s);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    p.d_gi[bt * G3 + g * Hd + gk] = nan;
+                    p.d_gh[bt * G3 + g * Hd + gk] = nan;
+                }
+            }
+        }
+        return;
+    }
+    if (gate) {
+        const float last = direct + ((red[(0 * 16 + gr) * 16 + gkl] + red[(1 * 16 + gr) * 16 + gkl]) +
+                                     (red[(2 * 16 + gr) * 16 + gkl] + red[(3 * 16 + gr) * 16 + gkl]));
+        p.dh0[(size_t)(row0 + gr) * Hd + gk] = last;
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------
 struct GruPlan { int KP, HP, NW, NG, NGpad, BL; };
 std::atomic<int> g_gru_mode{0};        // ddsp_gru_set_mode: bit 0 = spread placement, bit 1 = fault injection (tests)
@@ -590,6 +907,30 @@ hipError_t launch_bwd(const GruParams &p, size_t lds, hipStream_t s)
     return hipGetLastError();
 }
 
+template <int KP>
+hipError_t launch_mfma(const GruParams &p, bool backward, hipStream_t s)
+{
+    constexpr int HS = 16 * KP + 4;
+    static bool attr[2][64] = {};
+    static int resident[2][64] = {};
+    const size_t lds = backward ? sizeof(float) * ((size_t)kMfmaRows * 3 * HS + 4 * 256 + 4) : sizeof(float) * ((size_t)kMfmaRows * HS + 12 * 256 + 4);
+    const unsigned grid = (unsigned)(p.NGpad * p.NW);
+    if (backward) {
+        hipError_t e = ddsp_allow_big_lds((const void *)gru_bwd_mfma_kernel<KP>, attr[1]);
+        if (e != hipSuccess) return e;
+        e = check_resident(gru_bwd_mfma_kernel<KP>, 256, lds, grid, resident[1]);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((gru_bwd_mfma_kernel<KP>), dim3(grid), dim3(256), lds, s, p);
+    } else {
+        hipError_t e = ddsp_allow_big_lds((const void *)gru_fwd_mfma_kernel<KP>, attr[0]);
+        if (e != hipSuccess) return e;
+        e = check_resident(gru_fwd_mfma_kernel<KP>, 256, lds, grid, resident[0]);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((gru_fwd_mfma_kernel<KP>), dim3(grid), dim3(256), lds, s, p);
+    }
+    return hipGetLastError();
+}
+
 // Shapes of a workgroup, chosen by same-box A/B (tools/ab_gru.sh): rows per register tile RT and row sets NRS (256 threads
 // each, holding the same weights, taking every other tile).  One wavefront per SIMD issues a VALU instruction every 4+
 // cycles, so the forward's 384 FMAs + reductions of a 4-row tile (1.45 us of a 2.4 us step by in-kernel timers) run faster
@@ -609,7 +950,8 @@ int run_gru(GruParams &p, void *scratch, bool backward, hipStream_t s)
     if (rc) return rc;
     GruPlan pl;
     const int mode = g_gru_mode.load(std::memory_order_relaxed);   // test hooks: one snapshot per launch
-    if (!plan_gru(p.B, p.Hd, cus, backward ? kMaxRowsBwd : kMaxRows, (mode & 1) != 0, &pl)) return DDSP_ERANGE;
+    const int max_rows = p.lowp ? kMfmaRows : (backward ? kMaxRowsBwd : kMaxRows);
+    if (!plan_gru(p.B, p.Hd, cus, max_rows, (mode & 1) != 0, &pl)) return DDSP_ERANGE;
     p.NG = pl.NG; p.NGpad = pl.NGpad; p.NW = pl.NW; p.BL = pl.BL;
     const int payloads = backward ? 3 : 1;
     const bool inject = (mode & 2) != 0;
@@ -639,15 +981,24 @@ int run_gru(GruParams &p, void *scratch, bool backward, hipStream_t s)
     p.xchg = (gu64 *)((char *)scratch + 256);
     e = hipMemsetAsync(scratch, 0, 256 + xchg_bytes(pl, payloads), s);
     if (e != hipSuccess) return (int)e;
-    const int RT = (backward && pl.BL > 2 && pl.BL <= 4) ? 4 : 2;
-    const int NRS = (pl.BL <= 2 || RT == 4) ? 1 : 2;
-    const int BLpad = (pl.BL + RT - 1) & ~(RT - 1);
-    const size_t lds = sizeof(float) * ((size_t)BLpad * payloads * pl.HP + 4);
-    switch (pl.KP) {
-        case 4: e = launch_gru<4>(p, backward, RT, NRS, lds, s); break;
-        case 8: e = launch_gru<8>(p, backward, RT, NRS, lds, s); break;
-        case 16: e = launch_gru<16>(p, backward, RT, NRS, lds, s); break;
-        default: e = launch_gru<32>(p, backward, RT, NRS, lds, s); break;
+    if (p.lowp) {
+        switch (pl.KP) {
+            case 4: e = launch_mfma<4>(p, backward, s); break;
+            case 8: e = launch_mfma<8>(p, backward, s); break;
+            case 16: e = launch_mfma<16>(p, backward, s); break;
+            default: e = launch_mfma<32>(p, backward, s); break;
+        }
+    } else {
+        const int RT = (backward && pl.BL > 2 && pl.BL <= 4) ? 4 : 2;
+        const int NRS = (pl.BL <= 2 || RT == 4) ? 1 : 2;
+        const int BLpad = (pl.BL + RT - 1) & ~(RT - 1);
+        const size_t lds = sizeof(float) * ((size_t)BLpad * payloads * pl.HP + 4);
+        switch (pl.KP) {
+            case 4: e = launch_gru<4>(p, backward, RT, NRS, lds, s); break;
+            case 8: e = launch_gru<8>(p, backward, RT, NRS, lds, s); break;
+            case 16: e = launch_gru<16>(p, backward, RT, NRS, lds, s); break;
+            default: e = launch_gru<32>(p, backward, RT, NRS, lds, s); break;
+        }
     }
     if (e == hipErrorCooperativeLaunchTooLarge) return DDSP_ERANGE;   // the grid cannot be resident at once on this device
     if (e == hipSuccess && capturing == hipStreamCaptureStatusNone) {
@@ -674,7 +1025,8 @@ extern "C" int ddsp_gru_max_batch(int Hd, int backward)
     if (!plan_gru(1, Hd, cus, 1, false, &pl)) return 0;
     int slots = cus / pl.NW;
     slots -= slots % 8;
-    return (slots - 1) * (backward ? kMaxRowsBwd : kMaxRows);   // also valid in the spread test mode
+    if (backward & 2) return (slots - 1) * kMfmaRows;           // bit 1: the bf16 matrix-core variants (<= 16 rows per group)
+    return (slots - 1) * ((backward & 1) ? kMaxRowsBwd : kMaxRows);   // also valid in the spread test mode
 }
 
 extern "C" int ddsp_gru_forward(const float *gi, const float *w_hh, const float *b_hh, const float *h0, float *y, float *hT,
@@ -700,6 +1052,32 @@ extern "C" int ddsp_gru_backward(const float *dy, const float *dhT, const float 
     p.gates = const_cast<float *>(gates); p.hn = const_cast<float *>(hn);
     p.d_gi = d_gi; p.d_gh = d_gh; p.dh0 = dh0;
     p.B = B; p.T = T; p.Hd = Hd;
+    return run_gru(p, scratch, true, (hipStream_t)stream);
+}
+
+extern "C" int ddsp_gru_forward_bf16(const float *gi, const float *w_hh, const float *b_hh, const float *h0, float *y, float *hT,
+                                     float *gates, float *hn, void *scratch, int B, int T, int Hd, void *stream)
+{
+    if (B == 0) return 0;
+    if (!gi || !w_hh || !y || !hT || !scratch || B < 0 || T <= 0 || Hd <= 0) return DDSP_EINVAL;
+    if ((gates == nullptr) != (hn == nullptr)) return DDSP_EINVAL;
+    GruParams p = {};
+    p.gi = gi; p.w_hh = w_hh; p.b_hh = b_hh; p.h0 = h0; p.y = y; p.hT = hT; p.gates = gates; p.hn = hn;
+    p.B = B; p.T = T; p.Hd = Hd; p.lowp = 1;
+    return run_gru(p, scratch, false, (hipStream_t)stream);
+}
+
+extern "C" int ddsp_gru_backward_bf16(const float *dy, const float *dhT, const float *w_hh, const float *h0, const float *y,
+                                      const float *gates, const float *hn, float *d_gi, float *d_gh, float *dh0, void *scratch,
+                                      int B, int T, int Hd, void *stream)
+{
+    if (B == 0) return 0;
+    if (!dy || !w_hh || !y || !gates || !hn || !d_gi || !d_gh || !dh0 || !scratch || B < 0 || T <= 0 || Hd <= 0) return DDSP_EINVAL;
+    GruParams p = {};
+    p.dy = dy; p.dhT = dhT; p.w_hh = w_hh; p.h0 = h0; p.y = const_cast<float *>(y);
+    p.gates = const_cast<float *>(gates); p.hn = const_cast<float *>(hn);
+    p.d_gi = d_gi; p.d_gh = d_gh; p.dh0 = dh0;
+    p.B = B; p.T = T; p.Hd = Hd; p.lowp = 1;
     return run_gru(p, scratch, true, (hipStream_t)stream);
 }
 

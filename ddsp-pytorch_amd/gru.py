@@ -50,9 +50,10 @@ def _raise_on_timeout(scratches, what: str) -> None:
                 "compute units. The outputs of the unfinished steps are NaN.")
 
 
-def gru_forward(gi, w_hh, b_hh, h0, save: bool, scratch_out: list | None = None):
+def gru_forward(gi, w_hh, b_hh, h0, save: bool, scratch_out: list | None = None, lowp: bool = False):
     """Raw launcher of ddsp_gru_forward. gi [B,T,3Hd] -> (y [B,T,Hd], hT [B,Hd], gates | None, hn | None).
-    `scratch_out` (tests): receives the scratch buffer of every launch, for `gru_status`."""
+    `scratch_out` (tests): receives the scratch buffer of every launch, for `gru_status`.
+    `lowp`: the bf16 matrix-core variant (ddsp_gru_forward_bf16; autocast callers)."""
     B, T, G3 = gi.shape
     Hd = G3 // 3
     L = _lib.lib()
@@ -63,14 +64,15 @@ def gru_forward(gi, w_hh, b_hh, h0, save: bool, scratch_out: list | None = None)
     if B == 0:
         return y, hT, gates, hn
     with torch.cuda.device(gi.device):
-        cap = L.ddsp_gru_max_batch(Hd, 0)
+        cap = L.ddsp_gru_max_batch(Hd, 2 if lowp else 0)
         if cap <= 0:
             raise _lib.DdspHipError(f"ddsp_gru_forward: hidden size {Hd} is not supported")
         stream = torch.cuda.current_stream().cuda_stream
+        launch = L.ddsp_gru_forward_bf16 if lowp else L.ddsp_gru_forward
         for lo in range(0, B, cap):                      # rows are independent: larger batches go in slices
             hi = min(B, lo + cap)
             scratch = torch.empty(L.ddsp_gru_scratch_bytes(hi - lo, Hd), device=gi.device, dtype=torch.uint8)
-            rc = L.ddsp_gru_forward(gi[lo:hi].data_ptr(), w_hh.data_ptr(), _ptr(b_hh), _ptr(h0[lo:hi]) if h0 is not None else None,
+            rc = launch(gi[lo:hi].data_ptr(), w_hh.data_ptr(), _ptr(b_hh), _ptr(h0[lo:hi]) if h0 is not None else None,
                                     y[lo:hi].data_ptr(), hT[lo:hi].data_ptr(), _ptr(gates[lo:hi]) if save else None,
                                     _ptr(hn[lo:hi]) if save else None, scratch.data_ptr(), hi - lo, T, Hd, stream)
             _lib.check(rc, "ddsp_gru_forward")
@@ -79,7 +81,7 @@ def gru_forward(gi, w_hh, b_hh, h0, save: bool, scratch_out: list | None = None)
     return y, hT, gates, hn
 
 
-def gru_backward(dy, dhT, w_hh, h0, y, gates, hn, scratch_out: list | None = None):
+def gru_backward(dy, dhT, w_hh, h0, y, gates, hn, scratch_out: list | None = None, lowp: bool = False):
     """Raw launcher of ddsp_gru_backward -> (d_gi [B,T,3Hd], d_gh [B,T,3Hd], dh0 [B,Hd])."""
     B, T, Hd = y.shape
     L = _lib.lib()
@@ -87,12 +89,13 @@ def gru_backward(dy, dhT, w_hh, h0, y, gates, hn, scratch_out: list | None = Non
     d_gh = torch.empty_like(gates)
     dh0 = torch.empty((B, Hd), device=y.device, dtype=torch.float32)
     with torch.cuda.device(y.device):
-        cap = L.ddsp_gru_max_batch(Hd, 1)
+        cap = L.ddsp_gru_max_batch(Hd, 3 if lowp else 1)
         stream = torch.cuda.current_stream().cuda_stream
+        launch = L.ddsp_gru_backward_bf16 if lowp else L.ddsp_gru_backward
         for lo in range(0, B, cap):
             hi = min(B, lo + cap)
             scratch = torch.empty(L.ddsp_gru_scratch_bytes(hi - lo, Hd), device=y.device, dtype=torch.uint8)
-            rc = L.ddsp_gru_backward(dy[lo:hi].data_ptr(), _ptr(dhT[lo:hi]) if dhT is not None else None, w_hh.data_ptr(),
+            rc = launch(dy[lo:hi].data_ptr(), _ptr(dhT[lo:hi]) if dhT is not None else None, w_hh.data_ptr(),
                                      _ptr(h0[lo:hi]) if h0 is not None else None, y[lo:hi].data_ptr(), gates[lo:hi].data_ptr(),
                                      hn[lo:hi].data_ptr(), d_gi[lo:hi].data_ptr(), d_gh[lo:hi].data_ptr(), dh0[lo:hi].data_ptr(),
                                      scratch.data_ptr(), hi - lo, T, Hd, stream)
@@ -119,7 +122,8 @@ class _Recurrence(torch.autograd.Function):
         h = None if h0 is None else h0.detach().contiguous().float()
         need = any(ctx.needs_input_grad)
         launched = [] if _debug else None
-        y, hT, gates, hn = gru_forward(gi.detach(), w, b, h, save=need, scratch_out=launched)
+        lowp = gemm_dtype is not None        # under autocast the recurrence's products run on the matrix cores in bf16 as well
+        y, hT, gates, hn = gru_forward(gi.detach(), w, b, h, save=need, scratch_out=launched, lowp=lowp)
         if _debug:
             _raise_on_timeout(launched, "ddsp_gru_forward")
         if need:
@@ -136,7 +140,7 @@ class _Recurrence(torch.autograd.Function):
         dy = torch.zeros_like(y) if dy is None else dy.contiguous().float()
         dhT = None if dhT is None else dhT.contiguous().float()
         launched = [] if _debug else None
-        d_gi, d_gh, dh0 = gru_backward(dy, dhT, w, h0, y, gates, hn, scratch_out=launched)
+        d_gi, d_gh, dh0 = gru_backward(dy, dhT, w, h0, y, gates, hn, scratch_out=launched, lowp=ctx.gemm_dtype is not None)
         if _debug:
             _raise_on_timeout(launched, "ddsp_gru_backward")
         dw = db = None

@@ -303,3 +303,52 @@ def test_gru_stacked_layers_match_torch_cpu():
         y0, _ = ref(x)
         y1, _ = mine(x.cuda())
     assert float((y1.cpu() - y0).abs().max()) <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,hd,with_h0", [(4, 30, 64, True), (32, 60, 512, False), (9, 17, 200, True), (40, 12, 512, True), (1, 32, 512, True)])
+def test_gru_bf16_matrix_core_variant_tracks_fp32(B, T, hd, with_h0):
+    """The autocast variants (ddsp_gru_*_bf16: bf16 MFMA products, fp32 everything else) against the fp32 kernels on the same
+    inputs: equal up to bf16 rounding of h and W in the products (|dh| ~ 1e-3), gradients with cosine >= 0.999; status 0."""
+    torch.manual_seed(B * 7 + hd)
+    gi = torch.randn(B, T, 3 * hd, device="cuda")
+    w = torch.randn(3 * hd, hd, device="cuda") * (1.0 / hd ** 0.5)
+    b = torch.randn(3 * hd, device="cuda") * 0.1
+    h0 = torch.randn(B, hd, device="cuda").tanh() if with_h0 else None
+    dy = torch.randn(B, T, hd, device="cuda")
+    dhT = torch.randn(B, hd, device="cuda")
+    ref = gru_mod.gru_forward(gi, w, b, h0, save=True)
+    used = []
+    got = gru_mod.gru_forward(gi, w, b, h0, save=True, scratch_out=used, lowp=True)
+    assert all(gru_mod.gru_status(s) == 0 for s in used)
+    for a, c, name in zip(ref, got, ("y", "hT", "gates", "hn")):
+        assert torch.isfinite(c).all(), name
+        assert float((a - c).abs().max()) <= 3e-2, (name, float((a - c).abs().max()))
+    assert float((ref[0] - got[0]).abs().mean()) <= 2e-3
+    # backward on the SAME saved forward tensors (isolates the backward products)
+    y, _, gates, hn = ref
+    rb = gru_mod.gru_backward(dy, dhT, w, h0, y, gates, hn)
+    used = []
+    gb = gru_mod.gru_backward(dy, dhT, w, h0, y, gates, hn, scratch_out=used, lowp=True)
+    assert all(gru_mod.gru_status(s) == 0 for s in used)
+    for a, c, name in zip(rb, gb, ("d_gi", "d_gh", "dh0")):
+        assert torch.isfinite(c).all(), name
+        cos = float((a * c).sum() / (a.norm() * c.norm() + 1e-30))
+        assert cos >= 0.999, (name, cos)
+        assert float((a - c).abs().max()) <= 5e-2 * float(a.abs().max()), name
+
+
+@pytest.mark.gpu
+def test_gru_module_under_autocast_uses_the_bf16_variant_and_trains():
+    torch.manual_seed(3)
+    ref, mine = _pair(24, 128, 77)
+    mine = mine.cuda()
+    x = torch.randn(6, 40, 24, device="cuda")
+    with torch.no_grad():
+        y32, _ = mine(x)
+    xg = x.clone().requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y16, h16 = mine(xg)
+    assert y16.dtype == torch.float32 and float((y16 - y32).abs().max()) <= 5e-2      # bf16 GEMM + bf16 recurrence products
+    y16.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mine.parameters()) and torch.isfinite(xg.grad).all()
