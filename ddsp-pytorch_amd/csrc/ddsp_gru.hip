@@ -981,7 +981,12 @@ int run_gru(GruParams &p, void *scratch, bool backward, hipStream_t s)
     p.xchg = (gu64 *)((char *)scratch + 256);
     e = hipMemsetAsync(scratch, 0, 256 + xchg_bytes(pl, payloads), s);
     if (e != hipSuccess) return (int)e;
-    if (p.lowp) {
+    // Measured (tools/microbench/gru_lowp_time.py, 512 units): with <= 4 rows per group a step is hand-off latency, and the
+    // matrix-core forward's extra LDS round trip for the partial tiles makes it SLOWER than the fp32 kernel (2.9 vs 2.4 us per
+    // step at batch 32) -- it wins from 8 rows per group on (3.4 vs 4.3 at batch 64); the backward wins everywhere (4.2 vs 4.8).
+    // The fp32 kernel is at least as accurate, so a low-precision forward at <= 4 rows per group simply takes it.
+    const bool use_mfma = p.lowp && (backward || pl.BL > 4);
+    if (use_mfma) {
         switch (pl.KP) {
             case 4: e = launch_mfma<4>(p, backward, s); break;
             case 8: e = launch_mfma<8>(p, backward, s); break;
