@@ -98,6 +98,11 @@ class FilteredNoise(nn.Module):
         # the state_dict (the reference has no such state): a resumed run that must not replay the stream passes a new `seed`.
         self._offset = 0
 
+    def reseed(self, seed: int, offset: int = 0) -> None:
+        """Restart the in-kernel (rng='device') stream: a resumed training run passes a fresh seed (or the offset it saved)
+        so that it does not replay the draws of its first steps."""
+        self.seed, self._offset = int(seed), int(offset)
+
     def forward(self, x, noise=None, out=None):
         """`out` (inference only): accumulate the noise into this [B, T*hop] buffer instead of returning a new one."""
         param = x['H']
