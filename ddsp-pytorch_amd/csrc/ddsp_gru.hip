@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <atomic>
 #include <mutex>
@@ -505,13 +506,15 @@ __device__ __forceinline__ bf16x8_t to_bf16x8(float4 a, float4 b)
 
 constexpr int kMfmaRows = 16;     // rows of one MFMA tile = the most batch rows a group may hold in these variants
 
+// Forward: the tile is turned round -- M = (unit, gate) packed four to a unit (r, z, n, pad), N = the group's rows -- so that one
+// wavefront owns 4 units over the WHOLE K range and each lane ends up with the three pre-activations of one (row, unit) pair
+// in its own accumulator registers: no partial tiles, no second barrier between the product and the publish.
 template <int KP>
 __global__ void __launch_bounds__(256, 1) gru_fwd_mfma_kernel(GruParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) float h_s[];   // [16][HS] h_{t-1} | red [4][3][16][16] | failure flag
-    constexpr int HP = 16 * KP, HS = HP + 4, NKS = HP / 32, KSW = (NKS + 3) / 4;
-    float *red = h_s + kMfmaRows * HS;
-    int *fail_s = reinterpret_cast<int *>(red + 4 * 3 * 256);
+    extern __shared__ __attribute__((aligned(16))) float h_s[];   // [16][HS] h_{t-1} | failure flag
+    constexpr int HP = 16 * KP, HS = HP + 4, NKS = HP / 32;
+    int *fail_s = reinterpret_cast<int *>(h_s + kMfmaRows * HS);
     const int group = blockIdx.x % p.NGpad, member = blockIdx.x / p.NGpad;
     if (group >= p.NG) return;
     const int row0 = group * p.BL;
@@ -522,26 +525,23 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_mfma_kernel(GruParams p)
     const int ln = lane & 15, kb = lane >> 4;
     const size_t G3 = (size_t)3 * Hd;
 
-    // B fragments: B[k = 32 s + 8 kb + i][col ln] = W_hh[g][unit member*16 + ln][k], k-steps s = wave + 4 si
-    bf16x8_t wb[3][KSW];
+    // A fragments (weights): row m = ln = 4 uq + g of the wavefront's tile, unit = member*16 + 4 wave + uq, gate g (3 = padding)
+    bf16x8_t wa[NKS];
     {
-        const int u = member * kUnits + ln;
+        const int uq = ln >> 2, g = ln & 3;
+        const int u = member * kUnits + 4 * wave + uq;
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int s = 0; s < NKS; ++s)
 #pragma unroll
-            for (int si = 0; si < KSW; ++si) {
-                const int s = wave + 4 * si;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int k = 32 * s + 8 * kb + i;
-                    const float v = (s < NKS && u < Hd && k < Hd) ? p.w_hh[((size_t)g * Hd + u) * Hd + k] : 0.0f;
-                    wb[g][si][i] = (__bf16)v;
-                }
+            for (int i = 0; i < 8; ++i) {
+                const int k = 32 * s + 8 * kb + i;
+                const float v = (g < 3 && u < Hd && k < Hd) ? p.w_hh[((size_t)g * Hd + u) * Hd + k] : 0.0f;
+                wa[s][i] = (__bf16)v;
             }
     }
-    // gate thread (row gr, unit gu) of this workgroup
-    const int gr = threadIdx.x >> 4, gul = threadIdx.x & 15;
-    const int gu = member * kUnits + gul;
+    // this lane's (row, unit): D column = ln = batch row, D rows 4 kb + i = (unit 4 wave + kb, gate i)
+    const int gr = ln;
+    const int gu = member * kUnits + 4 * wave + kb;
     const bool gate = gr < nrows && gu < Hd;
     float bh[3];
 #pragma unroll
@@ -579,39 +579,29 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_mfma_kernel(GruParams p)
 #pragma unroll
             for (int g = 0; g < 3; ++g) pre[g] = p.gi[bt1 * G3 + g * Hd + gu];
         }
-        f32x4_t acc[3];
+        // B fragments (h_{t-1}, column = batch row ln), two accumulation chains
+        // (rows >= nrows of h_s stay zero from the start: the loads are unconditional, so that all of them are in flight
+        //  together instead of one exec-masked, waited-for pair per k-step)
+        bf16x8_t hb[NKS];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int si = 0; si < KSW; ++si) {
-            const int s = wave + 4 * si;
-            if (s < NKS) {   // wave-uniform
-                float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0;
-                if (ln < nrows) {
-                    a0 = *reinterpret_cast<const float4 *>(h_s + ln * HS + 32 * s + 8 * kb);
-                    a1 = *reinterpret_cast<const float4 *>(h_s + ln * HS + 32 * s + 8 * kb + 4);
-                }
-                const bf16x8_t a = to_bf16x8(a0, a1);
-#pragma unroll
-                for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wb[g][si], acc[g], 0, 0, 0);
-            }
+        for (int s = 0; s < NKS; ++s) {
+            const float4 b0 = *reinterpret_cast<const float4 *>(h_s + ln * HS + 32 * s + 8 * kb);
+            const float4 b1 = *reinterpret_cast<const float4 *>(h_s + ln * HS + 32 * s + 8 * kb + 4);
+            hb[s] = to_bf16x8(b0, b1);
         }
-        // D: row 4 kb + i, col ln
+        f32x4_t acc0 = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) red[((wave * 3 + g) * 16 + 4 * kb + i) * 16 + ln] = acc[g][i];
-        __syncthreads();
+        for (int s = 0; s < NKS; ++s) {
+            if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s], hb[s], acc1, 0, 0, 0);
+            else       acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s], hb[s], acc0, 0, 0, 0);
+        }
+        __syncthreads();   // every wavefront has read h_s: the next sweep may overwrite it
         if (gate) {
-            float sg[3];
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-                sg[g] = (red[((0 * 3 + g) * 16 + gr) * 16 + gul] + red[((1 * 3 + g) * 16 + gr) * 16 + gul]) +
-                        (red[((2 * 3 + g) * 16 + gr) * 16 + gul] + red[((3 * 3 + g) * 16 + gr) * 16 + gul]);
+            const float sr = acc0[0] + acc1[0], sz = acc0[1] + acc1[1], sn = acc0[2] + acc1[2];
             const size_t bt = (size_t)(row0 + gr) * p.T + t;
-            const float ghn = sg[2] + bh[2];
-            const float r = sigmoidf_(gir + (sg[0] + bh[0]));
-            const float z = sigmoidf_(giz + (sg[1] + bh[1]));
+            const float ghn = sn + bh[2];
+            const float r = sigmoidf_(gir + (sr + bh[0]));
+            const float z = sigmoidf_(giz + (sz + bh[1]));
             const float n = tanhf_(__fmaf_rn(r, ghn, gin));
             const float hnew = __fmaf_rn(hp - n, z, n);
             if (t < fault_from) publish(xg + ((size_t)(t & 1) * p.BL + gr) * HP + gu, (unsigned)t + 1u, hnew);
@@ -624,8 +614,6 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_mfma_kernel(GruParams p)
             if (p.hn) p.hn[bt * Hd + gu] = ghn;
             if (t == p.T - 1) p.hT[(size_t)(row0 + gr) * Hd + gu] = hnew;
         }
-        // (no barrier here: the next sweep rewrites h_s, which nobody reads any more in this step, and `red` is only rewritten
-        //  behind the next step's first barrier, which the gate threads reach after their reads)
     }
     __syncthreads();
     if (*fail_s) {
@@ -764,12 +752,10 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_mfma_kernel(GruParams p)
             const int ks = wave + 4 * si;
             if (ks < NKS) {   // wave-uniform
                 const int g = ks / (HP / 32), sb = ks - g * (HP / 32);
-                float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0;
-                if (ln < nrows) {
-                    const float *src = d_s + (ln * 3 + g) * HS + 32 * sb + 8 * kb;
-                    a0 = *reinterpret_cast<const float4 *>(src);
-                    a1 = *reinterpret_cast<const float4 *>(src + 4);
-                }
+                // (rows >= nrows of d_s stay zero from the start: unconditional loads, all in flight together)
+                const float *src = d_s + (ln * 3 + g) * HS + 32 * sb + 8 * kb;
+                const float4 a0 = *reinterpret_cast<const float4 *>(src);
+                const float4 a1 = *reinterpret_cast<const float4 *>(src + 4);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(to_bf16x8(a0, a1), wb[si], acc, 0, 0, 0);
             }
         }
@@ -913,7 +899,7 @@ hipError_t launch_mfma(const GruParams &p, bool backward, hipStream_t s)
     constexpr int HS = 16 * KP + 4;
     static bool attr[2][64] = {};
     static int resident[2][64] = {};
-    const size_t lds = backward ? sizeof(float) * ((size_t)kMfmaRows * 3 * HS + 4 * 256 + 4) : sizeof(float) * ((size_t)kMfmaRows * HS + 12 * 256 + 4);
+    const size_t lds = backward ? sizeof(float) * ((size_t)kMfmaRows * 3 * HS + 4 * 256 + 4) : sizeof(float) * ((size_t)kMfmaRows * HS + 4);
     const unsigned grid = (unsigned)(p.NGpad * p.NW);
     if (backward) {
         hipError_t e = ddsp_allow_big_lds((const void *)gru_bwd_mfma_kernel<KP>, attr[1]);
@@ -981,11 +967,11 @@ int run_gru(GruParams &p, void *scratch, bool backward, hipStream_t s)
     p.xchg = (gu64 *)((char *)scratch + 256);
     e = hipMemsetAsync(scratch, 0, 256 + xchg_bytes(pl, payloads), s);
     if (e != hipSuccess) return (int)e;
-    // Measured (tools/microbench/gru_lowp_time.py, 512 units): with <= 4 rows per group a step is hand-off latency, and the
-    // matrix-core forward's extra LDS round trip for the partial tiles makes it SLOWER than the fp32 kernel (2.9 vs 2.4 us per
-    // step at batch 32) -- it wins from 8 rows per group on (3.4 vs 4.3 at batch 64); the backward wins everywhere (4.2 vs 4.8).
-    // The fp32 kernel is at least as accurate, so a low-precision forward at <= 4 rows per group simply takes it.
-    const bool use_mfma = p.lowp && (backward || pl.BL > 4);
+    // Measured (tools/microbench/gru_lowp_time.py, 512 units, us per step fp32 -> bf16): forward 2.4 -> 2.0 at batch 32, 4.3 -> 2.8 at 64,
+    // 8.1 -> 5.9 at 128; backward 4.8 -> 3.5, 7.5 -> 5.1, 16.0 -> 10.6.  With ONE row per group (batch <= 8, the live callback) a step
+    // is pure hand-off latency and the forward ties or loses (1.75 -> 1.76 at batch 8, 2.3 -> 2.6 at batch 1): the fp32 kernel, which
+    // is at least as accurate, is taken there.
+    const bool use_mfma = p.lowp && (backward || pl.BL >= 2);
     if (use_mfma) {
         switch (pl.KP) {
             case 4: e = launch_mfma<4>(p, backward, s); break;
