@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from . import dense
 from .filtered_noise import FilteredNoise
 from .gru import GRU
 from .harmonic_oscillator import OscillatorBank
@@ -101,7 +102,7 @@ def _run_stack(stack: nn.Module, x: torch.Tensor) -> torch.Tensor:
             # x * w^T + b as one fp32 elementwise pass, also under autocast
             x = torch.addcmul(linear.bias.float(), x.float(), linear.weight.float().view(-1))
         else:
-            x = linear(x)
+            x = dense.linear(x, linear.weight, linear.bias)
         D = x.shape[-1]
         if (x.is_cuda and x.dtype in _FUSED_DTYPES and D % 256 == 0 and D <= 1024 and norm.elementwise_affine
                 and norm.bias is not None and act.negative_slope > 0):
@@ -164,8 +165,10 @@ class Controller(nn.Module):
         z = torch.cat((z_pitch, z_loud), dim=-1)
         z, state = self.gru(z, hidden) if hidden is not None else self.gru(z)
         z = _run_stack(self.mlp_gru, torch.cat((z, z_pitch, z_loud), dim=-1))
-        controls = dict(f0=batch['f0'], c=scaled_sigmoid(self.dense_harmonic(z)), hidden=state,
-                        H=scaled_sigmoid(self.dense_filter(z)), a=scaled_sigmoid(self.dense_loudness(z)))
+        def head(layer):
+            return scaled_sigmoid(dense.linear(z, layer.weight, layer.bias))
+
+        controls = dict(f0=batch['f0'], c=head(self.dense_harmonic), hidden=state, H=head(self.dense_filter), a=head(self.dense_loudness))
         if hidden is not None:
             return controls, hidden    # the INPUT state, as the reference returns it
         return controls

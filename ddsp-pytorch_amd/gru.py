@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+from . import dense
 
 
 _debug = os.environ.get("DDSP_GRU_DEBUG", "0") not in ("", "0")
@@ -149,9 +150,8 @@ class _Recurrence(torch.autograd.Function):
             h_prev = torch.cat((first.unsqueeze(1), y[:, :-1]), dim=1)          # h_{t-1} for every step
             a, b_ = d_gh.reshape(B * T, 3 * Hd), h_prev.reshape(B * T, Hd)
             if ctx.gemm_dtype is not None:                                      # the forward ran under autocast: so does this GEMM
-                dw = (a.to(ctx.gemm_dtype).t() @ b_.to(ctx.gemm_dtype)).float()
-            else:
-                dw = a.t() @ b_                                                 # library GEMM [3Hd, BT] x [BT, Hd]
+                a, b_ = a.to(ctx.gemm_dtype), b_.to(ctx.gemm_dtype)
+            dw = dense.weight_grad(a, b_)                                       # library GEMMs [3Hd, BT] x [BT, Hd], split over BT
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = d_gh.sum(dim=(0, 1))
         return d_gi, dw, db, (dh0 if ctx.needs_input_grad[3] else None), None
@@ -177,7 +177,7 @@ class GRU(nn.GRU):
         for layer in range(self.num_layers):     # decoder.py:60-65 `num_layers=conf.decoder_gru_layers`: stacked, layer by layer
             b_ih = getattr(self, f"bias_ih_l{layer}", None) if self.bias else None
             b_hh = getattr(self, f"bias_hh_l{layer}", None) if self.bias else None
-            gi = F.linear(x, getattr(self, f"weight_ih_l{layer}"), b_ih)
+            gi = dense.linear(x, getattr(self, f"weight_ih_l{layer}"), b_ih)
             x, hT = _Recurrence.apply(gi, getattr(self, f"weight_hh_l{layer}"), b_hh, None if hx is None else hx[layer], amp)
             finals.append(hT)
             if self.dropout > 0 and self.training and layer + 1 < self.num_layers:
