@@ -467,3 +467,44 @@ def test_fused_layernorm_16bit_activations_equal_fp32_pass_up_to_rounding(dtype)
     # the 16-bit pass sees y rounded to 16 bits only for the sign of the activation: the parameter gradients are the same sums
     assert float((dg16 - dg32).abs().max()) <= 1e-4 * float(dg32.abs().max())
     assert float((db16 - db32).abs().max()) <= 1e-4 * float(db32.abs().max())
+
+
+def test_dense_linear_is_plain_linear_on_cpu():
+    from ddsp_pytorch_amd import dense
+    torch.manual_seed(1)
+    x = torch.randn(5, 7, 6, requires_grad=True)
+    lin = nn.Linear(6, 4)
+    y = dense.linear(x, lin.weight, lin.bias)
+    assert torch.equal(y, lin(x))
+    g = torch.randn(3000, 9)
+    a = torch.randn(3000, 11)
+    assert torch.allclose(dense.weight_grad(g, a), g.t() @ a, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dense_linear_split_weight_gradient_matches_autograd(dtype):
+    """`dense.linear`: library GEMMs forward / input gradient, weight gradient as eight batched GEMMs over the rows + a sum.
+    Against torch's own Linear autograd on the same tensors: identical forward, gradients to summation-order rounding; under
+    autocast the GEMMs run in bf16 and the parameter gradients come back fp32."""
+    from ddsp_pytorch_amd import dense
+    torch.manual_seed(2)
+    lin = nn.Linear(512, 512).cuda()
+    x0 = torch.randn(32, 500, 512, device="cuda")
+    w = torch.randn(32, 500, 512, device="cuda")
+
+    def run(fn, amp):
+        lin.zero_grad()
+        x = x0.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            y = fn(x)
+        (y.float() * w).sum().backward()
+        return y.detach().float(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()
+
+    amp = dtype == torch.bfloat16
+    ref = run(lambda x: lin(x), amp)
+    got = run(lambda x: dense.linear(x, lin.weight, lin.bias), amp)
+    tol = 2e-2 if amp else 2e-5
+    assert got[2].dtype == torch.float32 and got[3].dtype == torch.float32
+    for a, c, name in zip(ref, got, ("y", "grad_x", "grad_w", "grad_b")):
+        assert float((a - c).abs().max()) <= tol * float(a.abs().max()), name
