@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the HIP path against the CPU oracle (tests/ hold the fixed cases; this is the wide net):
+random batch / frames / harmonics / hop / sample rate / noise bands, both f0 kinds, power-of-two and odd hops, hops 256 / 512
+(in-LDS FFT noise form, impulse shorter than / equal to / longer than the hop).  Prints one line per case and a summary;
+exit code 1 if any case exceeds the tolerances the tests assert (audio 1e-5, noise 2e-6 of max(1, |y|), phases bit-exact).
+usage: fuzz_parity.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ddsp_pytorch_amd as ddsp  # noqa: E402
+from ddsp_pytorch_amd import synthetic as syn  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+    worst_osc = worst_noise = 0.0
+    bad = 0
+    for i in range(cases):
+        hop = int(rng.choice([1, 2, 3, 7, 16, 48, 64, 100, 128, 160, 256, 441, 480, 512, 1024]))
+        sr = int(rng.choice([8000, 16000, 22050, 44100, 48000]))
+        H = int(rng.integers(1, 241))
+        B = int(rng.integers(1, 5))
+        T = int(rng.integers(1, max(2, min(60, 40000 // (hop * max(1, H // 8) + 1) + 2))))
+        kind = "musical" if rng.random() < 0.5 else "all_live"
+        shape = syn.SynthShape("fz", B, sr, hop, T, H, 2)
+        ctl = syn.make_controls(shape, int(rng.integers(1 << 30)), kind)
+        if rng.random() < 0.2:
+            ctl["f0"][0, T // 2:, 0] = 0.0                         # a silent stretch
+        if rng.random() < 0.2:
+            ctl["c"][:, :, rng.integers(0, H)] = 0.0                # an exactly-zero harmonic
+        ref, dbg = oracle.osc_forward(ctl["f0"], ctl["c"], ctl["a"], hop, sr, debug=True)
+        dev = {k: torch.from_numpy(v).cuda() for k, v in ctl.items()}
+        small = B * T * hop * H <= 4_000_000
+        y, _, phi = ddsp.osc_forward(dev["f0"], dev["c"], dev["a"], hop, sr, debug_phases=small)
+        y2, _, _ = ddsp.osc_forward(dev["f0"], dev["c"], dev["a"], hop, sr)      # production (FAST) kernels
+        ok_phi = True if not small else np.array_equal(bits(phi.cpu().numpy()), bits(dbg["phi"]))
+        fin = np.isfinite(ref)
+        e_osc = float(np.max(np.abs(y2.cpu().numpy() - ref)[fin])) if fin.any() else 0.0
+        same_nan = np.array_equal(np.isnan(ref), np.isnan(y2.cpu().numpy()))
+        # noise
+        nhop = int(rng.choice([8, 16, 40, 64, 128, 256, 256, 512, 512, 512]))
+        F = int(rng.integers(2, min(300, 2 * nhop) + 1))
+        Hn = syn.controller_range(rng.standard_normal((B, T, F), dtype=np.float32))
+        u = rng.random((B, T, nhop), dtype=np.float32)
+        nref = oracle.noise_forward(Hn, u, nhop)
+        ny = ddsp.noise_forward(torch.from_numpy(Hn).cuda(), nhop, uniform=torch.from_numpy(u).cuda())
+        e_noise = float(np.max(np.abs(ny.cpu().numpy() - nref))) / max(1.0, float(np.max(np.abs(nref))))
+        okay = ok_phi and same_nan and e_osc <= 1e-5 and e_noise <= 2e-6
+        bad += not okay
+        worst_osc, worst_noise = max(worst_osc, e_osc), max(worst_noise, e_noise)
+        print(f"{'ok ' if okay else 'BAD'} osc B{B} T{T} H{H} hop{hop} sr{sr} {kind}: phases {'bit-exact' if ok_phi else 'DIFFER'}"
+              f"{'' if small else ' (not dumped)'}, |dy| {e_osc:.1e} | noise hop{nhop} F{F}: {e_noise:.1e}", flush=True)
+    print(f"cases {cases}, failed {bad}, worst audio error {worst_osc:.2e}, worst noise error {worst_noise:.2e}")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
