@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Times the hot path on every single-GPU configuration of BASELINE.json (cfg1..cfg3 + the cfg4 shard) and
-checks a slice of each against the CPU oracle.  Prints one JSON object per config (not the bench.py contract:
-bench.py stays on the metric's configuration)."""
+"""Times the hot path on every single-GPU configuration of BASELINE.json (cfg1..cfg3 + the cfg4 shard) and the live
+callbacks.  Prints one JSON object per config (not the bench.py contract: bench.py stays on the metric's configuration).
+Parity of these shapes is the tests' business (tests/test_gpu_full_size.py: whole rows against the oracle)."""
 import json
 import os
 import sys
@@ -14,7 +14,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ddsp_pytorch_amd as ddsp  # noqa: E402
 from ddsp_pytorch_amd import synthetic as syn  # noqa: E402
-from oracle import oracle  # noqa: E402
 
 
 def run(shape, seed, steps=5):
@@ -38,15 +37,11 @@ def run(shape, seed, steps=5):
     for name, ms in ddsp._lib.profile_read():
         rec.setdefault(name, []).append(ms)
     ddsp._lib.profile_enable(0)
-    # parity of row 0 (oscillator only, injected-noise parity is covered by the tests)
-    yo, _, _ = ddsp.osc_forward(x["f0"][:1], x["c"][:1], x["a"][:1], shape.hop, shape.sample_rate)
-    ref = oracle.osc_forward(ctl["f0"][:1], ctl["c"][:1], ctl["a"][:1], shape.hop, shape.sample_rate)
-    err = float(np.max(np.abs(yo.cpu().numpy() - ref)))
+    assert bool(torch.isfinite(y).all())
     print(json.dumps({"config": shape.name, "batch": shape.batch, "sample_rate": shape.sample_rate, "hop": shape.hop,
                       "harmonics": shape.n_harmonics, "noise_bands": shape.n_noise_filters, "ms_per_step": 1e3 * el,
                       "samples_per_s": shape.batch * shape.samples / el,
-                      "kernel_ms": {k: round(float(np.mean(v)), 4) for k, v in rec.items()},
-                      "max_abs_err_row0_vs_oracle": err}), flush=True)
+                      "kernel_ms": {k: round(float(np.mean(v)), 4) for k, v in rec.items()}}), flush=True)
 
 
 def run_live(calls=200):
