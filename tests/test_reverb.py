@@ -132,3 +132,35 @@ def test_reverb_hip_live_matches_torch_formulation(sr, n):
     assert dev.buffer.data_ptr() == address                        # static address: the callback can live in a hipGraph
     with pytest.raises(ddsp._lib.DdspHipError):
         dev.live_forward(torch.zeros(1, sr + 1, device="cuda"))    # longer than the history: outside the reference's semantics
+
+
+def _check_g16(device, tol_y, tol_g):
+    """Fixtures G16 (round 2), straight from the reference: three live callbacks against a 16 000-sample history, and the
+    reference's own autograd of `forward` for a padded and a cropped clip."""
+    g = load_golden("g16_reverb_live_16k")
+    rv = make(g, device)
+    with torch.no_grad():
+        for k in range(3):
+            y = rv.live_forward(torch.from_numpy(g[f"x_{k}"]).to(device))
+            assert np.max(np.abs(y.cpu().numpy() - g[f"y_{k}"])) <= tol_y * max(1.0, np.max(np.abs(g[f"y_{k}"]))), k
+    assert np.array_equal(rv.buffer.detach().cpu().numpy(), g["buffer_last"])
+    for clip in (3000, 1200):
+        g = load_golden(f"g16_reverb_grad_clip{clip}")
+        rv = make(g, device)
+        x = torch.from_numpy(g["x"]).to(device).requires_grad_()
+        y = rv(x)
+        (y * torch.from_numpy(g["w"]).to(device)).sum().backward()
+        assert np.max(np.abs(y.detach().cpu().numpy() - g["y"])) <= tol_y * max(1.0, np.max(np.abs(g["y"])))
+        for name, got in (("grad_x", x.grad), ("grad_noise", rv.noise.grad), ("grad_decay", rv.decay.grad), ("grad_wet", rv.wet.grad)):
+            ref = g[name]
+            err = float(np.max(np.abs(got.detach().cpu().numpy() - ref)))
+            assert err <= tol_g * max(1.0, float(np.max(np.abs(ref)))), (clip, name, err)
+
+
+def test_reverb_reference_fixtures_round2_cpu():
+    _check_g16("cpu", 2e-6, 2e-5)
+
+
+@pytest.mark.gpu
+def test_reverb_reference_fixtures_round2_gpu():
+    _check_g16("cuda", 5e-6, 5e-5)

@@ -386,9 +386,40 @@ def g15():
     save("g15_decoder_gradients", **batch, **arrays, **grads, weight=weight, y=y.detach().numpy())
 
 
+
+def g16():
+    """Round 2: the reverb at realistic lengths and its autograd, straight from the reference (reverb.py:24-49).
+    * live: three `live_forward` callbacks of 512 samples against a 16 000-sample history (the HIP path computes the last n
+      outputs directly instead of the 2L-point FFT convolution);
+    * grad: d(sum(y * w)) / d(x, noise, decay, wet) of `forward` for a padded (clip > sample_rate) and a cropped clip."""
+    rng = np.random.default_rng(116)
+    conf = Conf(1, 16000, 64)
+    torch.manual_seed(16)
+    rv = RefReverb(conf, initial_wet=0.4, initial_decay=3.0)
+    arrays = dict(noise=rv.noise.numpy(), decay=rv.decay.numpy(), wet=rv.wet.numpy())
+    for call in range(3):
+        x = rng.standard_normal((1, 512)).astype(np.float32)
+        arrays[f"x_{call}"] = x
+        arrays[f"y_{call}"] = rv.live_forward(t(x)).numpy()
+    arrays["buffer_last"] = rv.buffer.detach().numpy().copy()
+    save("g16_reverb_live_16k", sample_rate=16000, **arrays)
+    torch.set_grad_enabled(True)
+    for clip in (3000, 1200):
+        conf = Conf(1, 2048, 64)
+        torch.manual_seed(17)
+        rv = RefReverb(conf, initial_wet=0.2, initial_decay=2.5)
+        x = torch.from_numpy(rng.standard_normal((2, clip)).astype(np.float32)).requires_grad_()
+        w = rng.standard_normal((2, clip)).astype(np.float32)
+        y = rv(x)
+        (y * t(w)).sum().backward()
+        save(f"g16_reverb_grad_clip{clip}", sample_rate=2048, x=x.detach().numpy(), w=w, noise=rv.noise.detach().numpy(),
+             decay=rv.decay.detach().numpy(), wet=rv.wet.detach().numpy(), y=y.detach().numpy(), grad_x=x.grad.numpy(),
+             grad_noise=rv.noise.grad.numpy(), grad_decay=rv.decay.grad.numpy(), grad_wet=rv.wet.grad.numpy())
+    torch.set_grad_enabled(False)
+
 if __name__ == "__main__":
     print("torch", torch.__version__, "threads", torch.get_num_threads())
-    only = sys.argv[1:]
-    for fn in (g1, g2_g3_g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15):
+    only = sys.argv[1:]                                       # e.g. `make_goldens.py g16`: just the named generators
+    for fn in (g1, g2_g3_g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16):
         if not only or fn.__name__ in only:
             fn()
