@@ -49,6 +49,36 @@ class _FusedSpectralL1(torch.autograd.Function):
         return grad * g, None, None, None
 
 
+class _Frames(torch.autograd.Function):
+    """x [B,N] -> windowed, reflect-padded frames [B, 1 + N // hop, n_fft] (contiguous) for a batched rfft: what torch.stft
+    does before its transform, as one HIP pass each way (include/ddsp_hip.h: ddsp_stft_frames*)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, window, n_fft, hop):
+        x = x.contiguous()
+        B, N = x.shape
+        frames = torch.empty((B, 1 + N // hop, n_fft), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ddsp_stft_frames(x.data_ptr(), window.data_ptr(), frames.data_ptr(), B, N, n_fft, hop,
+                                                   torch.cuda.current_stream().cuda_stream), "ddsp_stft_frames")
+        ctx.save_for_backward(window)
+        ctx.meta = (B, N, n_fft, hop)
+        return frames
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, grad_frames):
+        (window,) = ctx.saved_tensors
+        B, N, n_fft, hop = ctx.meta
+        grad_frames = grad_frames.contiguous().float()
+        grad_x = torch.empty((B, N), device=grad_frames.device, dtype=torch.float32)
+        with torch.cuda.device(grad_frames.device):
+            _lib.check(_lib.lib().ddsp_stft_frames_backward(grad_frames.data_ptr(), window.data_ptr(), grad_x.data_ptr(), B, N, n_fft, hop,
+                                                            torch.cuda.current_stream().cuda_stream), "ddsp_stft_frames_backward")
+        return grad_x, None, None, None
+
+
 def _dense_ri(spec: torch.Tensor) -> torch.Tensor:
     """Complex STFT -> dense float view [..., 2] without a copy when the memory is dense in some axis order
     (torch.stft returns the transpose of a contiguous [B, frames, bins] tensor); the loss is a sum over bins, so any
@@ -75,12 +105,22 @@ class SpectralLoss(nn.Module):
         spec = self.stft(x)
         return spec.real.square() + spec.imag.square()
 
+    def stft_ri(self, x: torch.Tensor) -> torch.Tensor:
+        """GPU: framing as one HIP pass, then ONE batched library rfft over contiguous frames -> dense re/im [B, frames, bins, 2]
+        (the same numbers as `stft`, frames-major, which is all a sum over the bins needs)."""
+        n = x.shape[-1]
+        if x.dim() == 2 and self.n_fft % 4 == 0 and n > self.n_fft // 2:
+            frames = _Frames.apply(x, self.window.to(device=x.device, dtype=torch.float32).contiguous(), self.n_fft, self.hop)
+            return torch.view_as_real(torch.fft.rfft(frames, dim=-1))
+        return _dense_ri(self.stft(x))
+
     def forward(self, x_pred, x_true):
         if x_pred.is_cuda and x_pred.dtype == torch.float32:
-            # GPU: the whole scale after the two library STFTs is one fused HIP pass (forward value + gradient)
+            # GPU: the whole scale around the two library FFTs is HIP -- framing (+ overlap-add in the backward) and one fused
+            # pass for the loss value and its gradient
             with torch.no_grad():
-                t_ri = _dense_ri(self.stft(x_true.float()))
-            p_ri = _dense_ri(self.stft(x_pred))
+                t_ri = self.stft_ri(x_true.float())
+            p_ri = self.stft_ri(x_pred)
             if p_ri.shape != t_ri.shape or p_ri.stride() != t_ri.stride():
                 raise ValueError("x_pred and x_true must have the same shape")
             return _FusedSpectralL1.apply(p_ri, t_ri, self.alpha, self.eps)

@@ -165,6 +165,17 @@ int ddsp_gru_set_mode(int mode);
 int ddsp_gru_set_fault_step(int step);
 
 /*
+ * Framing of the multi-scale spectral loss (loss/mss_loss.py:11-33 on torch.stft semantics: center=True, reflect padding,
+ * window of n_fft taps, frames = 1 + N / hop): everything around the batched library FFT of one scale.
+ *   ddsp_stft_frames           x [B,N] -> frames [B, frames, n_fft] = x[reflect(f*hop + j - n_fft/2)] * window[j], contiguous
+ *   ddsp_stft_frames_backward  grad_frames -> grad_x [B,N]: overlap-add and the padding's adjoint as a gather (deterministic)
+ * n_fft % 4 == 0, n_fft <= 8192, N > n_fft / 2.
+ */
+int ddsp_stft_frames(const float *x, const float *window, float *frames, long B, long N, int n_fft, int hop, void *stream);
+int ddsp_stft_frames_backward(const float *grad_frames, const float *window, float *grad_x, long B, long N, int n_fft, int hop,
+                              void *stream);
+
+/*
  * Reverb (model/ddsp/reverb.py:8-49).  noise [length], t [length] (seconds), decay / wet: one device
  * float each (the module's parameters, read on the device: nothing is synchronised).
  *

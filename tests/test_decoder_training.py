@@ -238,6 +238,30 @@ def test_fused_spectral_loss_matches_torch_formulation():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_fft,n,batch", [(2048, 16000, 3), (1024, 16000, 2), (512, 4099, 2), (256, 1000, 1), (128, 65, 2),
+                                           (64, 33, 3), (64, 64000, 1), (2048, 1025, 1)])
+def test_stft_framing_kernels_equal_torch_stft(n_fft, n, batch):
+    """ddsp_stft_frames (+ the library rfft) gives torch.stft's numbers (center / reflect / periodic Hann, hop n_fft/4:
+    loss/mss_loss.py:17-25), and ddsp_stft_frames_backward the gradient torch.stft's autograd gives -- including signals
+    barely longer than the padding (both mirrors overlap) and lengths that are no multiple of the hop."""
+    from ddsp_pytorch_amd.training import SpectralLoss
+    torch.manual_seed(n_fft + n)
+    sl = SpectralLoss(n_fft).cuda()
+    x = torch.randn(batch, n, device="cuda")
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    got = sl.stft_ri(xa)                                         # [B, frames, bins, 2]
+    ref = torch.view_as_real(sl.stft(xb)).transpose(1, 2)        # torch.stft: [B, bins, frames] complex
+    assert got.shape == ref.shape
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-6 * scale
+    w = torch.randn_like(got)
+    (got * w).sum().backward()
+    (ref * w).sum().backward()
+    assert float((xa.grad - xb.grad).abs().max()) <= 2e-6 * float(xb.grad.abs().max())
+
+
+@pytest.mark.gpu
 def test_fused_scaled_sigmoid_matches_torch_formulation():
     from ddsp_pytorch_amd.decoder import scaled_sigmoid
     torch.manual_seed(5)
