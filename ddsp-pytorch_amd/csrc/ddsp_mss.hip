@@ -69,6 +69,15 @@ __global__ void __launch_bounds__(256) spectral_finish_kernel(const float *__res
 
 }  // namespace
 
+namespace ddsp_mss {
+// shared with ddsp_mss_fft.hip: the fp64 finish of a scale's per-workgroup partial sums -> out3 = {loss, linear term, log term}
+hipError_t launch_finish(const float *partials, int blocks, float alpha, double inv_n, float *out3, hipStream_t s)
+{
+    hipLaunchKernelGGL(spectral_finish_kernel, dim3(1), dim3(256), 0, s, partials, blocks, alpha, inv_n, out3);
+    return hipGetLastError();
+}
+}  // namespace ddsp_mss
+
 extern "C" size_t ddsp_spectral_loss_scratch_bytes(void) { return sizeof(float) * 2 * kBlocks; }
 
 extern "C" int ddsp_spectral_loss(const float *pred_ri, const float *true_ri, float *grad_ri, void *scratch, float *out3,

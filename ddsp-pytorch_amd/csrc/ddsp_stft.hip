@@ -65,7 +65,8 @@ __device__ __forceinline__ float gather_position(const float *__restrict__ g, co
 }
 
 __global__ void __launch_bounds__(256) stft_frames_bwd_kernel(const float *__restrict__ grad_frames, const float *__restrict__ window,
-                                                              float *__restrict__ grad_x, long B, long N, int n_fft, int hop, long F)
+                                                              float *__restrict__ grad_x, long B, long N, int n_fft, int hop, long F,
+                                                              int accumulate)
 {
     extern __shared__ float win_s[];
     for (int j = threadIdx.x; j < n_fft; j += 256) win_s[j] = window[j];
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(256) stft_frames_bwd_kernel(const float *__res
         if (m >= 1 && m <= half) s += gather_position(g, win_s, half - m, n_fft, hop, F);
         const long pm = half + 2 * (N - 1) - m;                   // > half + N - 1 and < N + n_fft  <=>  N - 1 - half <= m <= N - 2
         if (m <= N - 2 && m >= N - 1 - half) s += gather_position(g, win_s, pm, n_fft, hop, F);
-        grad_x[e] = s;
+        grad_x[e] = accumulate ? grad_x[e] + s : s;
     }
 }
 
@@ -104,13 +105,13 @@ extern "C" int ddsp_stft_frames(const float *x, const float *window, float *fram
 }
 
 extern "C" int ddsp_stft_frames_backward(const float *grad_frames, const float *window, float *grad_x, long B, long N, int n_fft, int hop,
-                                         void *stream)
+                                         int accumulate, void *stream)
 {
     if (B == 0) return 0;
     if (!grad_frames || !window || !grad_x || B < 0 || N <= 0 || n_fft <= 0 || hop <= 0) return DDSP_EINVAL;
     if (n_fft % 4 != 0 || n_fft > 8192 || N <= n_fft / 2) return DDSP_ERANGE;
     const long F = 1 + N / hop;
     hipLaunchKernelGGL(stft_frames_bwd_kernel, dim3(grid_for(B * N)), dim3(256), sizeof(float) * (size_t)n_fft, (hipStream_t)stream,
-                       grad_frames, window, grad_x, B, N, n_fft, hop, F);
+                       grad_frames, window, grad_x, B, N, n_fft, hop, F, accumulate);
     return (int)hipGetLastError();
 }

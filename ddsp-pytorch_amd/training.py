@@ -75,8 +75,46 @@ class _Frames(torch.autograd.Function):
         grad_x = torch.empty((B, N), device=grad_frames.device, dtype=torch.float32)
         with torch.cuda.device(grad_frames.device):
             _lib.check(_lib.lib().ddsp_stft_frames_backward(grad_frames.data_ptr(), window.data_ptr(), grad_x.data_ptr(), B, N, n_fft, hop,
-                                                            torch.cuda.current_stream().cuda_stream), "ddsp_stft_frames_backward")
+                                                            0, torch.cuda.current_stream().cuda_stream), "ddsp_stft_frames_backward")
         return grad_x, None, None, None
+
+
+class _FusedScales(torch.autograd.Function):
+    """Sum over scales of the spectral loss of two waveforms [B, L], each scale ONE HIP kernel from the waveforms to the loss
+    partials and the gradient frames (in-LDS transforms; include/ddsp_hip.h: ddsp_mss_scale) plus the overlap-add gather of
+    ddsp_stft_frames_backward accumulating into one d loss / d x_pred, which the backward only scales.
+    `scales`: tuple of (n_fft, hop, window tensor, alpha, eps).  The target carries no gradient."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x_pred, x_true, scales):
+        L = _lib.lib()
+        x_pred, x_true = x_pred.contiguous(), x_true.contiguous()
+        B, n = x_pred.shape
+        dev = x_pred.device
+        need = ctx.needs_input_grad[0]
+        out = torch.empty((len(scales), 3), device=dev, dtype=torch.float32)
+        scratch = torch.empty(L.ddsp_mss_scale_scratch_bytes(), device=dev, dtype=torch.uint8)
+        grad_x = torch.empty_like(x_pred) if need else None
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream().cuda_stream
+            for i, (n_fft, hop, window, alpha, eps) in enumerate(scales):
+                frames = torch.empty((B * (1 + n // hop), n_fft), device=dev, dtype=torch.float32) if need else None
+                _lib.check(L.ddsp_mss_scale(x_pred.data_ptr(), x_true.data_ptr(), window.data_ptr(),
+                                            None if frames is None else frames.data_ptr(), scratch.data_ptr(), out[i].data_ptr(),
+                                            B, n, n_fft, hop, float(alpha), float(eps), stream), "ddsp_mss_scale")
+                if need:
+                    _lib.check(L.ddsp_stft_frames_backward(frames.data_ptr(), window.data_ptr(), grad_x.data_ptr(), B, n, n_fft, hop,
+                                                           1 if i else 0, stream), "ddsp_stft_frames_backward")
+        if need:
+            ctx.save_for_backward(grad_x)
+        return out[:, 0].sum()
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        (grad_x,) = ctx.saved_tensors
+        return grad_x * g, None, None
 
 
 def _dense_ri(spec: torch.Tensor) -> torch.Tensor:
@@ -114,9 +152,19 @@ class SpectralLoss(nn.Module):
             return torch.view_as_real(torch.fft.rfft(frames, dim=-1))
         return _dense_ri(self.stft(x))
 
+    def fused_scale(self, x: torch.Tensor):
+        """(n_fft, hop, window, alpha, eps) when this scale can run as ONE HIP kernel on `x` (ddsp_mss_scale), else None."""
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0 and x.shape[1] > self.n_fft // 2 and self.hop > 0
+                and _lib.lib().ddsp_mss_scale_supported(self.n_fft)):
+            return (self.n_fft, self.hop, self.window.to(device=x.device, dtype=torch.float32).contiguous(), self.alpha, self.eps)
+        return None
+
     def forward(self, x_pred, x_true):
         if x_pred.is_cuda and x_pred.dtype == torch.float32:
-            # GPU: the whole scale around the two library FFTs is HIP -- framing (+ overlap-add in the backward) and one fused
+            scale = self.fused_scale(x_pred)
+            if scale is not None and x_true.shape == x_pred.shape and not x_true.requires_grad:
+                return _FusedScales.apply(x_pred, x_true.float(), (scale,))
+            # other shapes / transform sizes: HIP framing (+ overlap-add in the backward) around the library FFTs and one fused
             # pass for the loss value and its gradient
             with torch.no_grad():
                 t_ri = self.stft_ri(x_true.float())
@@ -140,6 +188,11 @@ class MSSLoss(nn.Module):
     def forward(self, x_pred, x_true):
         if isinstance(x_true, dict):
             x_true = x_true["audio"]
+        if x_pred.is_cuda and x_pred.dtype == torch.float32 and x_true.shape == x_pred.shape and not x_true.requires_grad:
+            scales = [loss.fused_scale(x_pred) for loss in self.losses]
+            if scales and all(s is not None for s in scales):
+                # every scale one HIP kernel (+ its overlap-add gather), all gradients accumulated into one buffer
+                return _FusedScales.apply(x_pred, x_true.float(), tuple(scales))
         return sum(loss(x_pred, x_true) for loss in self.losses)
 
 

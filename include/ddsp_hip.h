@@ -168,12 +168,27 @@ int ddsp_gru_set_fault_step(int step);
  * Framing of the multi-scale spectral loss (loss/mss_loss.py:11-33 on torch.stft semantics: center=True, reflect padding,
  * window of n_fft taps, frames = 1 + N / hop): everything around the batched library FFT of one scale.
  *   ddsp_stft_frames           x [B,N] -> frames [B, frames, n_fft] = x[reflect(f*hop + j - n_fft/2)] * window[j], contiguous
- *   ddsp_stft_frames_backward  grad_frames -> grad_x [B,N]: overlap-add and the padding's adjoint as a gather (deterministic)
+ *   ddsp_stft_frames_backward  grad_frames -> grad_x [B,N]: overlap-add and the padding's adjoint as a gather (deterministic;
+ *                              accumulate != 0 adds to grad_x)
  * n_fft % 4 == 0, n_fft <= 8192, N > n_fft / 2.
  */
 int ddsp_stft_frames(const float *x, const float *window, float *frames, long B, long N, int n_fft, int hop, void *stream);
 int ddsp_stft_frames_backward(const float *grad_frames, const float *window, float *grad_x, long B, long N, int n_fft, int hop,
-                              void *stream);
+                              int accumulate, void *stream);
+
+/*
+ * One whole scale of the multi-scale spectral loss (loss/mss_loss.py:17-31: spectrogram of both signals, mean |P - Q| +
+ * alpha * mean |log2(Q + eps) - log2(P + eps)|) in one kernel, transforms included (in-LDS FFTs; n_fft a power of two in
+ * [64, 2048], L > n_fft / 2, torch.stft center / reflect semantics with the given window and hop):
+ *   out3        {loss, linear term, log term} of this scale
+ *   grad_frames nullable; [B * (1 + L / hop), n_fft] = d loss / d (windowed frame of x_pred), to be folded back onto the
+ *               waveform with ddsp_stft_frames_backward (which applies the window)
+ *   scratch     ddsp_mss_scale_scratch_bytes() bytes
+ */
+size_t ddsp_mss_scale_scratch_bytes(void);
+int ddsp_mss_scale_supported(int n_fft);
+int ddsp_mss_scale(const float *x_pred, const float *x_true, const float *window, float *grad_frames, void *scratch, float *out3,
+                   long B, long L, int n_fft, int hop, float alpha, float eps, void *stream);
 
 /*
  * Reverb (model/ddsp/reverb.py:8-49).  noise [length], t [length] (seconds), decay / wet: one device
