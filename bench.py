@@ -128,7 +128,7 @@ def train_mode(args, rank, world, dist):
     torch.manual_seed(0)                                     # identical replicas on every rank
     model = ddsp.Decoder(TrainConf, noise_rng="device", seed=rank).cuda()
     loss_fn = ddsp.MSSLoss().cuda()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)      # one multi-tensor kernel for the whole update
     rng = np.random.default_rng(2000 + rank)
     batch = {"normalized_cents": torch.from_numpy(rng.uniform(0, 1, (b, frames, 1)).astype(np.float32)).cuda(),
              "loudness": torch.from_numpy(rng.uniform(-1, 1, (b, frames, 1)).astype(np.float32)).cuda(),

@@ -84,8 +84,8 @@ __device__ __forceinline__ unsigned long long pack_granule(unsigned epoch, float
 // A thread owns columns tid and tid + NT (NT = workgroup size) of every row; rows are polled RB at a time (2 RB independent loads in
 // flight per lane), and a batch whose tags all matched is not polled again.  Returns false (wave-uniform) on
 // timeout / abort.
-template <int RB, bool FIRST_LIGHT>
-__device__ __forceinline__ bool sweep_rows(gu64 *src, float *dst, int rows, int Hd, int HP, unsigned epoch, gu32 *status, int NT,
+template <int RB, bool FIRST_LIGHT, typename DT = float>
+__device__ __forceinline__ bool sweep_rows(gu64 *src, DT *dst, int rows, int Hd, int HP, unsigned epoch, gu32 *status, int NT,
                                            long spin_ticks, int DS = 0)
 {
     if (DS == 0) DS = HP;                                 // destination row stride in LDS (the granule rows are HP apart)
@@ -136,7 +136,7 @@ __device__ __forceinline__ bool sweep_rows(gu64 *src, float *dst, int rows, int 
                     if (row < rows) {
 #pragma unroll
                         for (int c = 0; c < 2; ++c)
-                            if (kc[c] < Hd) dst[row * DS + kc[c]] = __uint_as_float((unsigned)x[r][c]);
+                            if (kc[c] < Hd) dst[row * DS + kc[c]] = (DT)__uint_as_float((unsigned)x[r][c]);
                     }
                 }
             }
@@ -154,6 +154,98 @@ __device__ __forceinline__ bool sweep_rows(gu64 *src, float *dst, int rows, int 
 __device__ __forceinline__ void publish(gu64 *dst, unsigned epoch, float v)
 {
     __hip_atomic_store(dst, pack_granule(epoch, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- packed granules of the bf16 matrix-core variants ----------------------------------------------------------------
+// The matrix cores consume bf16 operands, so the hand-off carries bf16: the polls' volume through the L2 -- what a step's time
+// grows with (measured: +0.27 us per batch row forward, +0.54 backward with one fp32 value per granule) -- shrinks 2x / 3x.
+//   PACK2  {epoch:32 | v1:16 | v0:16}            forward: h of batch rows 2r and 2r+1, one unit
+//   PACK3  {epoch:16 | v2:16 | v1:16 | v0:16}    backward: the three gate-gradient payloads of one (row, unit); epochs < 2^16
+__device__ __forceinline__ unsigned bf16_bits(float v)
+{
+    const __bf16 b = (__bf16)v;     // round to nearest even, as the fragments' conversion did before
+    return (unsigned)__builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ void publish2(gu64 *dst, unsigned epoch, float v0, float v1)
+{
+    const unsigned long long g = ((unsigned long long)epoch << 32) | ((unsigned long long)bf16_bits(v1) << 16) | (unsigned long long)bf16_bits(v0);
+    __hip_atomic_store(dst, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void publish3(gu64 *dst, unsigned epoch, float v0, float v1, float v2)
+{
+    const unsigned long long g = ((unsigned long long)(epoch & 0xffffu) << 48) | ((unsigned long long)bf16_bits(v2) << 32) |
+                                 ((unsigned long long)bf16_bits(v1) << 16) | (unsigned long long)bf16_bits(v0);
+    __hip_atomic_store(dst, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// (Tried on top, same-process A/B at 512 units: the backward WITHOUT first light 2.72 -> 3.05 us per step at batch 32, and two sets of polls
+//  in flight half a round trip apart 1.83 -> 2.24 forward / 2.72 -> 3.29 backward -- every extra poll slows the L2 for the publishers.)
+// sweep_rows for packed granules: `rows` granule rows of width Hd (stride HP); PACK values of each granule go to the bf16 LDS image at
+// dst[(row * PACK + i) * DS + column] (PACK2: image rows 2r, 2r+1 = batch rows; PACK3: image rows 3r + gate).
+template <int RB, bool FIRST_LIGHT, int PACK>
+__device__ __forceinline__ bool sweep_packed(gu64 *src, unsigned short *dst, int rows, int Hd, int HP, unsigned epoch, gu32 *status,
+                                             long spin_ticks, int DS)
+{
+    constexpr int NT = 256;
+    constexpr int TAG_SHIFT = PACK == 3 ? 48 : 32;
+    const unsigned want = PACK == 3 ? (epoch & 0xffffu) : epoch;
+    const long t0 = wall_clock64();
+    const int kc[2] = {(int)threadIdx.x, (int)threadIdx.x + NT};
+    const int nb = (rows + RB - 1) / RB;
+    unsigned todo = (1u << nb) - 1u;
+    if (FIRST_LIGHT && kc[0] < Hd) {
+        gu64 *sentinel = src + (size_t)(rows - 1) * HP + kc[0];
+        for (unsigned pass = 0;; ++pass) {
+            const unsigned long long x = __hip_atomic_load(sentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((unsigned)(x >> TAG_SHIFT) == want)) break;
+            if ((pass & 63) == 63) {
+                if (wall_clock64() - t0 > spin_ticks) return false;
+                if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    for (unsigned pass = 0;; ++pass) {
+        for (int bi = 0; bi < nb; ++bi) {
+            if (!((todo >> bi) & 1u)) continue;           // wave-uniform
+            unsigned long long x[RB][2];
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int row = bi * RB + r;
+                    x[r][c] = (unsigned long long)want << TAG_SHIFT;
+                    if (row < rows && kc[c] < Hd)
+                        x[r][c] = __hip_atomic_load(src + (size_t)row * HP + kc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            bool ok = true;
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) ok = ok && (unsigned)(x[r][c] >> TAG_SHIFT) == want;
+            if (__all(ok)) {
+                todo &= ~(1u << bi);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    const int row = bi * RB + r;
+                    if (row < rows) {
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                            if (kc[c] < Hd) {
+#pragma unroll
+                                for (int i = 0; i < PACK; ++i) dst[(row * PACK + i) * DS + kc[c]] = (unsigned short)(x[r][c] >> (16 * i));
+                            }
+                    }
+                }
+            }
+        }
+        if (todo == 0u) return true;
+        if ((pass & 63) == 63) {
+            if (wall_clock64() - t0 > spin_ticks) return false;
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------
@@ -512,9 +604,10 @@ constexpr int kMfmaRows = 16;     // rows of one MFMA tile = the most batch rows
 template <int KP>
 __global__ void __launch_bounds__(256, 1) gru_fwd_mfma_kernel(GruParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) float h_s[];   // [16][HS] h_{t-1} | failure flag
-    constexpr int HP = 16 * KP, HS = HP + 4, NKS = HP / 32;
-    int *fail_s = reinterpret_cast<int *>(h_s + kMfmaRows * HS);
+    // [16][HS] h_{t-1} as the matrix cores take it (bf16: the poller converts each value once, a B fragment is one 16-byte read) | failure flag
+    extern __shared__ __attribute__((aligned(16))) __bf16 h_bf[];
+    constexpr int HP = 16 * KP, HS = HP + 8, NKS = HP / 32;
+    int *fail_s = reinterpret_cast<int *>(h_bf + kMfmaRows * HS);
     const int group = blockIdx.x % p.NGpad, member = blockIdx.x / p.NGpad;
     if (group >= p.NG) return;
     const int row0 = group * p.BL;
@@ -549,12 +642,14 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_mfma_kernel(GruParams p)
 
     for (int i = threadIdx.x; i < kMfmaRows * HS; i += 256) {
         const int bl = i / HS, k = i - bl * HS;
-        h_s[i] = (bl < nrows && k < Hd && p.h0) ? p.h0[(size_t)(row0 + bl) * Hd + k] : 0.0f;
+        h_bf[i] = (__bf16)((bl < nrows && k < Hd && p.h0) ? p.h0[(size_t)(row0 + bl) * Hd + k] : 0.0f);
     }
+    float hp = (gate && p.h0) ? p.h0[(size_t)(row0 + gr) * Hd + gu] : 0.0f;   // this lane's own h_{t-1}, fp32 (the blend needs it unrounded)
     if (threadIdx.x == 0) *fail_s = 0;
     __syncthreads();
 
-    gu64 *xg = p.xchg + (size_t)group * 2 * p.BL * HP;  // [2][BL][HP]
+    const int PRW = (p.BL + 1) / 2;                      // granule rows: batch rows 2r and 2r+1 share a granule (PACK2)
+    gu64 *xg = p.xchg + (size_t)group * 2 * PRW * HP;    // [2][PRW][HP]
     float pre[3] = {0.0f, 0.0f, 0.0f};
     if (gate) {
         const size_t bt = (size_t)(row0 + gr) * p.T;
@@ -565,14 +660,13 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_mfma_kernel(GruParams p)
     int t_reached = 0;
     for (int t = 0; t < p.T; ++t) {
         if (t > 0) {
-            const bool ok = sweep_rows<4, false>(xg + (size_t)((t - 1) & 1) * p.BL * HP, h_s, nrows, Hd, HP, (unsigned)t, p.status, 256,
-                                                 p.spin_ticks, HS);
+            const bool ok = sweep_packed<4, false, 2>(xg + (size_t)((t - 1) & 1) * PRW * HP, reinterpret_cast<unsigned short *>(h_bf), (nrows + 1) / 2,
+                                                      Hd, HP, (unsigned)t, p.status, p.spin_ticks, HS);
             if (!ok && (threadIdx.x & 63) == 0) *fail_s = 1;
         }
         __syncthreads();
         if (*fail_s) break;
         t_reached = t + 1;
-        const float hp = gate ? h_s[gr * HS + gu] : 0.0f;
         const float gir = pre[0], giz = pre[1], gin = pre[2];
         if (gate && t + 1 < p.T) {
             const size_t bt1 = (size_t)(row0 + gr) * p.T + t + 1;
@@ -580,22 +674,19 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_mfma_kernel(GruParams p)
             for (int g = 0; g < 3; ++g) pre[g] = p.gi[bt1 * G3 + g * Hd + gu];
         }
         // B fragments (h_{t-1}, column = batch row ln), two accumulation chains
-        // (rows >= nrows of h_s stay zero from the start: the loads are unconditional, so that all of them are in flight
+        // (rows >= nrows of h_bf stay zero from the start: the loads are unconditional, so that all of them are in flight
         //  together instead of one exec-masked, waited-for pair per k-step)
         bf16x8_t hb[NKS];
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            const float4 b0 = *reinterpret_cast<const float4 *>(h_s + ln * HS + 32 * s + 8 * kb);
-            const float4 b1 = *reinterpret_cast<const float4 *>(h_s + ln * HS + 32 * s + 8 * kb + 4);
-            hb[s] = to_bf16x8(b0, b1);
-        }
+        for (int s = 0; s < NKS; ++s) hb[s] = *reinterpret_cast<const bf16x8_t *>(h_bf + ln * HS + 32 * s + 8 * kb);
         f32x4_t acc0 = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
             if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s], hb[s], acc1, 0, 0, 0);
             else       acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s], hb[s], acc0, 0, 0, 0);
         }
-        __syncthreads();   // every wavefront has read h_s: the next sweep may overwrite it
+        __syncthreads();   // every wavefront has read h_bf: the next sweep may overwrite it
+        float hnew = 0.0f;
         if (gate) {
             const float sr = acc0[0] + acc1[0], sz = acc0[1] + acc1[1], sn = acc0[2] + acc1[2];
             const size_t bt = (size_t)(row0 + gr) * p.T + t;
@@ -603,8 +694,8 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_mfma_kernel(GruParams p)
             const float r = sigmoidf_(gir + (sr + bh[0]));
             const float z = sigmoidf_(giz + (sz + bh[1]));
             const float n = tanhf_(__fmaf_rn(r, ghn, gin));
-            const float hnew = __fmaf_rn(hp - n, z, n);
-            if (t < fault_from) publish(xg + ((size_t)(t & 1) * p.BL + gr) * HP + gu, (unsigned)t + 1u, hnew);
+            hnew = __fmaf_rn(hp - n, z, n);
+            hp = hnew;
             p.y[bt * Hd + gu] = hnew;
             if (p.gates) {
                 p.gates[bt * G3 + gu] = r;
@@ -613,6 +704,13 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_mfma_kernel(GruParams p)
             }
             if (p.hn) p.hn[bt * Hd + gu] = ghn;
             if (t == p.T - 1) p.hT[(size_t)(row0 + gr) * Hd + gu] = hnew;
+        }
+        // hand-off: the lane of the even batch row takes its right-hand neighbour's value (row gr + 1, same unit; 0 past the last
+        // row) with one DPP move and publishes the pair
+        {
+            const float nb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, hnew), 0x101 /* row_shl:1 */, 0xf, 0xf, true));
+            if (gate && (gr & 1) == 0 && t < fault_from)
+                publish2(xg + ((size_t)(t & 1) * PRW + (gr >> 1)) * HP + gu, (unsigned)t + 1u, hnew, nb);
         }
     }
     __syncthreads();
@@ -638,9 +736,9 @@ __global__ void __launch_bounds__(256, 1) gru_fwd_mfma_kernel(GruParams p)
 template <int KP>
 __global__ void __launch_bounds__(256, 1) gru_bwd_mfma_kernel(GruParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) float d_s[];   // [16][3][HS] gate gradients | red [4][16][16] | failure flag
-    constexpr int HP = 16 * KP, HS = HP + 4, NKS = 3 * HP / 32, KSW = (NKS + 3) / 4;
-    float *red = d_s + kMfmaRows * 3 * HS;
+    extern __shared__ __attribute__((aligned(16))) __bf16 d_bf[];   // [16][3][HS] gate gradients (bf16, as the matrix cores take them) | red [4][16][16] fp32 | failure flag
+    constexpr int HP = 16 * KP, HS = HP + 8, NKS = 3 * HP / 32, KSW = (NKS + 3) / 4;
+    float *red = reinterpret_cast<float *>(d_bf + kMfmaRows * 3 * HS);
     int *fail_s = reinterpret_cast<int *>(red + 4 * 256);
     const int group = blockIdx.x % p.NGpad, member = blockIdx.x / p.NGpad;
     if (group >= p.NG) return;
@@ -669,12 +767,12 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_mfma_kernel(GruParams p)
             }
         }
     }
-    for (int i = threadIdx.x; i < kMfmaRows * 3 * HS; i += 256) d_s[i] = 0.0f;
+    for (int i = threadIdx.x; i < kMfmaRows * 3 * HS; i += 256) d_bf[i] = (__bf16)0.0f;
     for (int i = threadIdx.x; i < 4 * 256; i += 256) red[i] = 0.0f;
     if (threadIdx.x == 0) *fail_s = 0;
     __syncthreads();
 
-    gu64 *xg = p.xchg + (size_t)group * 2 * p.BL * 3 * HP;  // [2][BL][3][HP]
+    gu64 *xg = p.xchg + (size_t)group * 2 * p.BL * HP;  // [2][BL][HP]: one PACK3 granule per (row, unit)
     // gate thread (row gr, column gk)
     const int gr = threadIdx.x >> 4, gkl = threadIdx.x & 15;
     const int gk = member * kUnits + gkl;
@@ -712,7 +810,7 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_mfma_kernel(GruParams p)
     for (int s = 0; s < p.T; ++s) {
         const int t = p.T - 1 - s;
         const unsigned epoch = (unsigned)s + 1u;
-        gu64 *slot = xg + (size_t)(s & 1) * p.BL * 3 * HP;
+        gu64 *slot = xg + (size_t)(s & 1) * p.BL * HP;
         // 1. dh of this step = dy + (what the previous step's product left in `red`) ; gate gradients; publish
         if (gate) {
             if (s > 0)
@@ -722,12 +820,7 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_mfma_kernel(GruParams p)
             const float dh = dyv + carry;
             const float dr_pre = dh * f_r, dz_pre = dh * f_z, dhn = dh * f_hn, dn_pre = dh * f_n;
             direct = dh * f_dir;
-            gu64 *gdst = slot + (size_t)gr * 3 * HP + gk;
-            if (s < fault_from) {
-                publish(gdst, epoch, dr_pre);
-                publish(gdst + HP, epoch, dz_pre);
-                publish(gdst + 2 * HP, epoch, dhn);
-            }
+            if (s < fault_from) publish3(slot + (size_t)gr * HP + gk, epoch, dr_pre, dz_pre, dhn);
             p.d_gi[bt * G3 + gk] = dr_pre;
             p.d_gi[bt * G3 + Hd + gk] = dz_pre;
             p.d_gi[bt * G3 + 2 * Hd + gk] = dn_pre;
@@ -738,7 +831,7 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_mfma_kernel(GruParams p)
         s_reached = s + 1;
         // 2. the group's gate gradients -> LDS (3 * nrows rows of width Hd)
         {
-            const bool ok = sweep_rows<12, true>(slot, d_s, 3 * nrows, Hd, HP, epoch, p.status, 256, p.spin_ticks, HS);
+            const bool ok = sweep_packed<4, true, 3>(slot, reinterpret_cast<unsigned short *>(d_bf), nrows, Hd, HP, epoch, p.status, p.spin_ticks, HS);
             if (!ok && (threadIdx.x & 63) == 0) *fail_s = 1;
         }
         __syncthreads();
@@ -752,16 +845,14 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_mfma_kernel(GruParams p)
             const int ks = wave + 4 * si;
             if (ks < NKS) {   // wave-uniform
                 const int g = ks / (HP / 32), sb = ks - g * (HP / 32);
-                // (rows >= nrows of d_s stay zero from the start: unconditional loads, all in flight together)
-                const float *src = d_s + (ln * 3 + g) * HS + 32 * sb + 8 * kb;
-                const float4 a0 = *reinterpret_cast<const float4 *>(src);
-                const float4 a1 = *reinterpret_cast<const float4 *>(src + 4);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(to_bf16x8(a0, a1), wb[si], acc, 0, 0, 0);
+                // (rows >= nrows of d_bf stay zero from the start: unconditional loads, all in flight together)
+                const bf16x8_t a = *reinterpret_cast<const bf16x8_t *>(d_bf + (ln * 3 + g) * HS + 32 * sb + 8 * kb);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wb[si], acc, 0, 0, 0);
             }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) red[(wave * 16 + 4 * kb + i) * 16 + ln] = acc[i];
-        __syncthreads();   // `red` complete (read at the top of the next step); d_s free for the next sweep
+        __syncthreads();   // `red` complete (read at the top of the next step); d_bf free for the next sweep
     }
     if (*fail_s) {
         if (threadIdx.x == 0) __hip_atomic_store(p.status, (unsigned)GRU_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -896,10 +987,11 @@ hipError_t launch_bwd(const GruParams &p, size_t lds, hipStream_t s)
 template <int KP>
 hipError_t launch_mfma(const GruParams &p, bool backward, hipStream_t s)
 {
-    constexpr int HS = 16 * KP + 4;
+    constexpr int HS = 16 * KP + 8;     // row stride of the bf16 image in LDS
     static bool attr[2][64] = {};
     static int resident[2][64] = {};
-    const size_t lds = backward ? sizeof(float) * ((size_t)kMfmaRows * 3 * HS + 4 * 256 + 4) : sizeof(float) * ((size_t)kMfmaRows * HS + 4);
+    const size_t lds = backward ? sizeof(__bf16) * (size_t)kMfmaRows * 3 * HS + sizeof(float) * (4 * 256 + 4)
+                                : sizeof(__bf16) * (size_t)kMfmaRows * HS + sizeof(float) * 4;
     const unsigned grid = (unsigned)(p.NGpad * p.NW);
     if (backward) {
         hipError_t e = ddsp_allow_big_lds((const void *)gru_bwd_mfma_kernel<KP>, attr[1]);
@@ -971,7 +1063,8 @@ int run_gru(GruParams &p, void *scratch, bool backward, hipStream_t s)
     // 8.1 -> 5.9 at 128; backward 4.8 -> 3.5, 7.5 -> 5.1, 16.0 -> 10.6.  With ONE row per group (batch <= 8, the live callback) a step
     // is pure hand-off latency and the forward ties or loses (1.75 -> 1.76 at batch 8, 2.3 -> 2.6 at batch 1): the fp32 kernel, which
     // is at least as accurate, is taken there.
-    const bool use_mfma = p.lowp && (backward || pl.BL >= 2);
+    // (the backward's packed granules carry 16-bit epochs: sequences of 65 536 steps and more take the fp32 kernels)
+    const bool use_mfma = p.lowp && (backward ? p.T < 65536 : pl.BL >= 2);
     if (use_mfma) {
         switch (pl.KP) {
             case 4: e = launch_mfma<4>(p, backward, s); break;

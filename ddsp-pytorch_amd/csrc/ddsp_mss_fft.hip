@@ -104,31 +104,56 @@ __device__ __forceinline__ void fft_lds(cf *&src, cf *&dst, const cf *__restrict
     }
 }
 
-__device__ __forceinline__ long reflect_index(long i, long L)
+__device__ __forceinline__ int reflect_index(int i, int L)
 {
     if (i < 0) i = -i;
     if (i >= L) i = 2 * (L - 1) - i;
     return i;
 }
 
-// z[slot * N + j] = x[b, frame 2q](j) w[j] + i x[b, frame 2q + 1](j) w[j] for pair (b, q) = divmod(pair0 + slot, pairs per row);
-// a frame past the row's last one (odd frame count) and pairs past the last row are zero
+// Where a slot's frame pair lives: filled once per workgroup iteration by the first SLOTS threads (the 64-bit divisions happen
+// there, not per point).
+struct SlotInfo {
+    long row;      // b * L: offset of the batch row in x
+    long frame;    // b * F + fa: flat index of the pair's first frame (gradient frames)
+    int start;     // fa * hop - N/2: position of point 0 of frame a in the row (frame b: + hop)
+    int nvalid;    // 0: no pair (past the last row), 1: frame a only (odd frame count), 2: both
+};
+
 template <int N, int PTS>
-__device__ __forceinline__ void load_pairs(cf *z, const float *__restrict__ x, const float *__restrict__ win_s, const MssParams &p,
-                                           long pair0, int tid)
+__device__ __forceinline__ void fill_slots(SlotInfo *slots, const MssParams &p, long pair0, int tid)
 {
-    const int half = N / 2;
+    if (tid < PTS / N) {
+        const long pair = pair0 + tid;
+        SlotInfo si;
+        si.row = 0; si.frame = 0; si.start = 0; si.nvalid = 0;
+        if (pair < p.npairs) {
+            const long b = pair / p.PR, fa = 2 * (pair - b * p.PR);
+            si.row = b * p.L;
+            si.frame = b * p.F + fa;
+            si.start = (int)(fa * p.hop) - N / 2;
+            si.nvalid = (fa + 1 < p.F) ? 2 : 1;
+        }
+        slots[tid] = si;
+    }
+}
+
+// z[slot * N + j] = x[b, frame 2q](j) w[j] + i x[b, frame 2q + 1](j) w[j]; a missing frame is zero
+template <int N, int PTS>
+__device__ __forceinline__ void load_pairs(cf *z, const float *__restrict__ x, const float *__restrict__ win_s, const SlotInfo *slots,
+                                           const MssParams &p, int tid)
+{
+    const int L = (int)p.L;
 #pragma unroll
     for (int e = 0; e < PTS / kThreads; ++e) {
         const int pt = tid + kThreads * e;
         const int slot = pt / N, j = pt & (N - 1);
-        const long pair = pair0 + slot;
+        const SlotInfo si = slots[slot];
         float re = 0.0f, im = 0.0f;
-        if (pair < p.npairs) {
-            const long b = pair / p.PR, fa = 2 * (pair - b * p.PR);
-            const float *row = x + b * p.L;
-            re = row[reflect_index(fa * p.hop + j - half, p.L)];
-            if (fa + 1 < p.F) im = row[reflect_index((fa + 1) * p.hop + j - half, p.L)];
+        if (si.nvalid > 0) {
+            const float *row = x + si.row;
+            re = row[reflect_index(si.start + j, L)];
+            if (si.nvalid > 1) im = row[reflect_index(si.start + p.hop + j, L)];
         }
         const float w = win_s[j];
         z[pt] = make_float2(re * w, im * w);
@@ -147,6 +172,7 @@ __global__ void __launch_bounds__(kThreads) mss_scale_kernel(MssParams p)
     cf *Zb = Y + PTS;
     cf *tw = Zb + PTS;                         // [N] e^{-2 pi i q / N}
     float *win_s = reinterpret_cast<float *>(tw + N);   // [N]
+    SlotInfo *slots = reinterpret_cast<SlotInfo *>(win_s + N);
     const int tid = threadIdx.x;
     for (int q = tid; q < N; q += kThreads) {
         float s, c;
@@ -159,8 +185,10 @@ __global__ void __launch_bounds__(kThreads) mss_scale_kernel(MssParams p)
     const float inv_ln2 = 1.4426950408889634f;
     float lin = 0.0f, lg = 0.0f;
     for (long pair0 = (long)blockIdx.x * SLOTS; pair0 < p.npairs; pair0 += (long)gridDim.x * SLOTS) {
-        load_pairs<N, PTS>(X, p.pred, win_s, p, pair0, tid);
-        load_pairs<N, PTS>(Y, p.truth, win_s, p, pair0, tid);
+        fill_slots<N, PTS>(slots, p, pair0, tid);
+        __syncthreads();
+        load_pairs<N, PTS>(X, p.pred, win_s, slots, p, tid);
+        load_pairs<N, PTS>(Y, p.truth, win_s, slots, p, tid);
         __syncthreads();
         cf *a = X, *b = Zb, *c = Y;
         fft_lds<N, PTS, false>(a, b, tw, tid);      // prediction's packed spectra -> a
@@ -202,13 +230,12 @@ __global__ void __launch_bounds__(kThreads) mss_scale_kernel(MssParams p)
             for (int e = 0; e < PTS / kThreads; ++e) {
                 const int pt = tid + kThreads * e;
                 const int slot = pt / N, j = pt & (N - 1);
-                const long pair = pair0 + slot;
-                if (pair < p.npairs) {
-                    const long b = pair / p.PR, fa = 2 * (pair - b * p.PR);
+                const SlotInfo si = slots[slot];
+                if (si.nvalid > 0) {
                     const cf y = a[pt];
-                    float *dst = p.grad_frames + (b * p.F + fa) * N + j;
+                    float *dst = p.grad_frames + si.frame * N + j;
                     dst[0] = y.x;
-                    if (fa + 1 < p.F) dst[N] = y.y;
+                    if (si.nvalid > 1) dst[N] = y.y;
                 }
             }
             __syncthreads();
@@ -230,7 +257,7 @@ hipError_t launch(const MssParams &p0, hipStream_t s, int *blocks_out)
 {
     constexpr int PTS = N > 1024 ? N : 1024;
     constexpr int SLOTS = PTS / N;
-    const size_t lds = sizeof(float2) * (3 * PTS + N) + sizeof(float) * N;
+    const size_t lds = sizeof(float2) * (3 * PTS + N) + sizeof(float) * N + sizeof(SlotInfo) * SLOTS;
     static bool raised = false;     // > 64 KiB of dynamic LDS needs the opt-in (n_fft = 2048: 72 KiB)
     if (lds > 64 * 1024 && !raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mss_scale_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -258,7 +285,7 @@ extern "C" int ddsp_mss_scale(const float *x_pred, const float *x_true, const fl
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) return (int)hipMemsetAsync(out3, 0, 3 * sizeof(float), s);   // an empty shard: the mean over no bins is reported as 0
     if (!x_pred || !x_true || !window || !scratch || B < 0 || hop <= 0) return DDSP_EINVAL;
-    if (!ddsp_mss_scale_supported(n_fft) || L <= n_fft / 2) return DDSP_ERANGE;
+    if (!ddsp_mss_scale_supported(n_fft) || L <= n_fft / 2 || L > (1l << 30) || (L / hop + 2) * (long)hop > (1l << 30)) return DDSP_ERANGE;   // 32-bit positions inside a row
     MssParams p;
     p.pred = x_pred; p.truth = x_true; p.window = window; p.grad_frames = grad_frames; p.partials = (float *)scratch;
     p.B = B; p.L = L; p.F = 1 + L / hop; p.hop = hop;

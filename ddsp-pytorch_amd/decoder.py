@@ -164,6 +164,10 @@ class Controller(nn.Module):
         z_loud = _run_stack(self.mlp_loudness, batch['loudness'])
         z = torch.cat((z_pitch, z_loud), dim=-1)
         z, state = self.gru(z, hidden) if hidden is not None else self.gru(z)
+        if z.dtype != z_pitch.dtype:
+            # torch.autocast: the recurrence hands back fp32, the stacks 16-bit activations.  One narrow cast of z here instead of
+            # cat widening both stacks to fp32 and the next Linear narrowing all three again (the Linear computes in 16 bit anyway)
+            z = z.to(z_pitch.dtype)
         z = _run_stack(self.mlp_gru, torch.cat((z, z_pitch, z_loud), dim=-1))
         def head(layer):
             return scaled_sigmoid(dense.linear(z, layer.weight, layer.bias))

@@ -8,8 +8,12 @@ autocast dtype (as F.linear would), the returned parameter gradients are fp32.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 import torch.nn.functional as F
+
+from . import _lib
 
 SPLIT = 8            # partial GEMMs of the weight gradient
 MIN_ROWS = 2048      # below this the plain GEMM is at least as fast
@@ -26,15 +30,80 @@ def weight_grad(gy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return (gy.t() @ x).float()
 
 
+_IO = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """[M, N] -> fp32 [N] = sum over the rows: a dense layer's bias gradient.  One streaming HIP pass on CUDA tensors
+    (include/ddsp_hip.h: ddsp_colsum; the stock reduction of a tall thin matrix costs 12-150 us per layer at the training shape)."""
+    if not (x.is_cuda and x.dim() == 2 and x.dtype in _IO):
+        return x.sum(0, dtype=torch.float32)
+    x = x.contiguous()
+    M, N = x.shape
+    out = torch.empty(N, device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    scratch = torch.empty(L.ddsp_colsum_scratch_bytes(N), device=x.device, dtype=torch.uint8)
+    with torch.cuda.device(x.device):
+        _lib.check(L.ddsp_colsum(x.data_ptr(), out.data_ptr(), scratch.data_ptr(), M, N, _IO[x.dtype],
+                                 torch.cuda.current_stream().cuda_stream), "ddsp_colsum")
+    return out
+
+
+class LowpWeights:
+    """Low-precision copies of the dense layers' parameters for torch.autocast steps, refreshed by ONE multi-tensor copy per
+    step instead of a cast launch per parameter and layer (31 launches at the training shape).  `refresh(dtype)` is called once
+    before the forward (train_step does) and renews the copies of every parameter `_Linear` has asked for so far; `_Linear` takes
+    a copy only while the parameter has not been written since (`_version` unchanged), so a stale copy can never be used."""
+
+    def __init__(self):
+        self._copies = {}      # id(param) -> [weakref(param), copy or None, version at refresh]
+
+    def refresh(self, dtype):
+        src, dst = [], []
+        for key, e in list(self._copies.items()):
+            p = e[0]()
+            if p is None:
+                del self._copies[key]
+                continue
+            if e[1] is None or e[1].dtype != dtype or e[1].shape != p.shape or e[1].device != p.device:
+                e[1], e[2] = torch.empty_like(p, dtype=dtype), -1
+            if e[2] != p._version:
+                src.append(p.detach())
+                dst.append(e[1])
+                e[2] = p._version
+        if src:
+            torch._foreach_copy_(dst, src)
+
+    def get(self, p, dtype):
+        e = self._copies.get(id(p))
+        if e is None or e[0]() is not p:
+            if p.is_cuda and p.dtype == torch.float32 and isinstance(p, torch.nn.Parameter):
+                self._copies[id(p)] = [weakref.ref(p), None, -1]       # wanted: part of the next refresh
+            return None
+        if e[1] is not None and e[2] == p._version and e[1].dtype == dtype:
+            return e[1]
+        return None
+
+
+lowp_weights = LowpWeights()
+
+
+def _cast(p, dt):
+    if p.dtype == dt:
+        return p
+    c = lowp_weights.get(p, dt)
+    return c if c is not None else p.to(dt)
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         dt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled("cuda")) else x.dtype
         if dt not in (torch.float32, torch.bfloat16, torch.float16):
             dt = torch.float32
-        xc, wc = x.to(dt), weight.to(dt)
+        xc, wc = x.to(dt), _cast(weight, dt)
         with torch.autocast("cuda", enabled=False):
-            y = F.linear(xc, wc, None if bias is None else bias.to(dt))
+            y = F.linear(xc, wc, None if bias is None else _cast(bias, dt))
         ctx.save_for_backward(xc, wc)
         ctx.has_bias = bias is not None
         ctx.in_dtype, ctx.param_dtype = x.dtype, weight.dtype
@@ -52,7 +121,7 @@ class _Linear(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 gw = weight_grad(g2, xc.reshape(-1, xc.shape[-1])).to(ctx.param_dtype)
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = g2.sum(0, dtype=torch.float32).to(ctx.param_dtype)
+                gb = colsum(g2).to(ctx.param_dtype)
         return gx, gw, gb
 
 

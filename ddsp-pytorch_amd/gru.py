@@ -153,7 +153,7 @@ class _Recurrence(torch.autograd.Function):
                 a, b_ = a.to(ctx.gemm_dtype), b_.to(ctx.gemm_dtype)
             dw = dense.weight_grad(a, b_)                                       # library GEMMs [3Hd, BT] x [BT, Hd], split over BT
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = d_gh.sum(dim=(0, 1))
+            db = dense.colsum(d_gh.reshape(B * T, 3 * Hd))
         return d_gi, dw, db, (dh0 if ctx.needs_input_grad[3] else None), None
 
 

@@ -18,6 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+from . import dense
 
 
 class _FusedSpectralL1(torch.autograd.Function):
@@ -239,6 +240,8 @@ def train_step(model: nn.Module, loss_fn: nn.Module, optimizer: torch.optim.Opti
             p.grad = torch.zeros_like(p)
         loss = torch.zeros((), device=params[0].device if params else "cpu")
     else:
+        if amp_dtype is not None:
+            dense.lowp_weights.refresh(amp_dtype)       # one multi-tensor cast of the dense layers' parameters per step
         with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
             audio = model(batch)
         loss = loss_fn(audio.float(), batch)

@@ -165,6 +165,13 @@ int ddsp_gru_set_mode(int mode);
 int ddsp_gru_set_fault_step(int step);
 
 /*
+ * Column sums of a row-major [M, N] matrix (fp32 io_type 0, bf16 DDSP_IO_BF16, fp16 DDSP_IO_F16) -> out [N] fp32: the bias
+ * gradient of the control network's dense layers (decoder.py:9-39, :60-72), deterministic.  scratch: ddsp_colsum_scratch_bytes(N).
+ */
+size_t ddsp_colsum_scratch_bytes(int N);
+int ddsp_colsum(const void *x, float *out, void *scratch, long M, int N, int io_type, void *stream);
+
+/*
  * Framing of the multi-scale spectral loss (loss/mss_loss.py:11-33 on torch.stft semantics: center=True, reflect padding,
  * window of n_fft taps, frames = 1 + N / hop): everything around the batched library FFT of one scale.
  *   ddsp_stft_frames           x [B,N] -> frames [B, frames, n_fft] = x[reflect(f*hop + j - n_fft/2)] * window[j], contiguous

@@ -567,3 +567,38 @@ def test_dense_linear_split_weight_gradient_matches_autograd(dtype):
     assert got[2].dtype == torch.float32 and got[3].dtype == torch.float32
     for a, c, name in zip(ref, got, ("y", "grad_x", "grad_w", "grad_b")):
         assert float((a - c).abs().max()) <= tol * float(a.abs().max()), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_colsum_kernel_equals_torch_sum(dtype):
+    """ddsp_colsum (the dense layers' bias gradients) against torch's fp64 column sums: the training shapes (16 000 rows x
+    512 / 1536 / 65 / 1 columns), row counts around the chunking (1, 63, 64, 65, 8191) and no rows at all."""
+    from ddsp_pytorch_amd import dense
+    torch.manual_seed(5)
+    for M, N in [(16000, 512), (16000, 1536), (16000, 65), (16000, 1), (1, 7), (63, 100), (64, 64), (65, 129), (8191, 3), (0, 5)]:
+        x = torch.randn(M, N, device="cuda").to(dtype)
+        got = dense.colsum(x)
+        ref = x.double().sum(0)
+        assert got.dtype == torch.float32 and got.shape == (N,)
+        tol = 2e-6 * max(1.0, float(x.double().abs().sum(0).max())) if M else 0.0
+        assert float((got.double() - ref).abs().max()) <= tol, (M, N)
+    assert torch.equal(dense.colsum(x), dense.colsum(x))            # fixed summation order
+
+
+@pytest.mark.gpu
+def test_lowp_weight_copies_are_never_stale():
+    """dense.LowpWeights: a copy is handed out only while the parameter is unchanged since the refresh."""
+    from ddsp_pytorch_amd import dense
+    w = nn.Parameter(torch.randn(8, 8, device="cuda"))
+    cache = dense.LowpWeights()
+    assert cache.get(w, torch.bfloat16) is None                     # first request: registered, not yet copied
+    cache.refresh(torch.bfloat16)
+    c = cache.get(w, torch.bfloat16)
+    assert c is not None and torch.equal(c, w.detach().bfloat16())
+    with torch.no_grad():
+        w.add_(1.0)                                                  # an optimiser step
+    assert cache.get(w, torch.bfloat16) is None
+    cache.refresh(torch.bfloat16)
+    assert torch.equal(cache.get(w, torch.bfloat16), w.detach().bfloat16())
+    assert cache.get(w, torch.float16) is None
