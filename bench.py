@@ -128,7 +128,7 @@ def train_mode(args, rank, world, dist):
     torch.manual_seed(0)                                     # identical replicas on every rank
     model = ddsp.Decoder(TrainConf, noise_rng="device", seed=rank).cuda()
     loss_fn = ddsp.MSSLoss().cuda()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)      # one multi-tensor kernel for the whole update
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=args.graph)      # one multi-tensor kernel for the whole update
     rng = np.random.default_rng(2000 + rank)
     batch = {"normalized_cents": torch.from_numpy(rng.uniform(0, 1, (b, frames, 1)).astype(np.float32)).cuda(),
              "loudness": torch.from_numpy(rng.uniform(-1, 1, (b, frames, 1)).astype(np.float32)).cuda(),
@@ -144,12 +144,22 @@ def train_mode(args, rank, world, dist):
     amp_dtype = {"none": None, "bf16": torch.bfloat16, "fp16": torch.float16}[args.amp]
     scaler = torch.amp.GradScaler("cuda") if args.amp == "fp16" else None
     nbytes = 0
+    if args.graph:
+        if scaler is not None:
+            raise SystemExit("--graph: bf16 or fp32 only")
+        graphed = ddsp.GraphedTrainStep(model, loss_fn, opt, batch, amp_dtype=amp_dtype)     # the whole step as hipGraph replays
+
+        def one_step():
+            return graphed.step()
+    else:
+        def one_step():
+            return ddsp.train_step(model, loss_fn, opt, batch, amp_dtype=amp_dtype, scaler=scaler)
     for _ in range(args.warmup):
-        _, nbytes = ddsp.train_step(model, loss_fn, opt, batch, amp_dtype=amp_dtype, scaler=scaler)
+        _, nbytes = one_step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, nbytes = ddsp.train_step(model, loss_fn, opt, batch, amp_dtype=amp_dtype, scaler=scaler)
+        loss, nbytes = one_step()
     submitted = time.perf_counter() - t0                     # host time to ISSUE the steps (nothing in a step synchronises)
     fence()
     elapsed = time.perf_counter() - t0
@@ -166,7 +176,7 @@ def train_mode(args, rank, world, dist):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.amp == "none" else f"{args.amp} GEMMs (autocast), f32 synthesis / loss / optimiser", "data": "synthetic",
             "config": {"workload": f"decoder (4.84 M params) + HIP synth + reverb + MSS loss (6 scales) + Adam, batch {b}/GPU, "
-                                   f"16 kHz, 100 harmonics, 65 noise bands, 4 s", "parallelism": f"dp{world}, one flat all-reduce",
+                                   f"16 kHz, 100 harmonics, 65 noise bands, 4 s", "parallelism": f"dp{world}, one flat all-reduce" + (", step captured as a hipGraph" if args.graph else ""),
                        "allreduce_bytes": nbytes},
             "final_loss": float(loss)}), flush=True)
     if dist is not None:
@@ -190,6 +200,8 @@ def main():
     ap.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"],
                     help="train mode: autocast dtype of the dense layers' GEMMs (reference: precision=16, train/train.py:50); "
                          "off by default, the synthesis kernels stay fp32 either way")
+    ap.add_argument("--graph", action="store_true",
+                    help="train mode: capture the whole step (forward, loss, backward, Adam) as hipGraph replays (GraphedTrainStep)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--one-device", action="store_true",

@@ -59,6 +59,8 @@ def lib():
     L.ddsp_osc_backward.argtypes = [vp] * 8 + [i32] * 5 + [vp]
     L.ddsp_noise_backward.restype = i32
     L.ddsp_noise_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, u64, u64, vp]
+    L.ddsp_noise_backward_counter.restype = i32
+    L.ddsp_noise_backward_counter.argtypes = [vp, vp, i32, i32, i32, i32, u64, vp, vp]
     L.ddsp_noise_set_generic.restype = i32
     L.ddsp_noise_set_generic.argtypes = [i32]
     L.ddsp_profile_enable.restype = i32
@@ -134,7 +136,7 @@ def lib():
 
 
 EXPORTS = ("ddsp_hip_abi_version", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_noise_forward", "ddsp_noise_forward_counter",
-           "ddsp_osc_backward_scratch_bytes", "ddsp_osc_backward", "ddsp_noise_backward",
+           "ddsp_osc_backward_scratch_bytes", "ddsp_osc_backward", "ddsp_noise_backward", "ddsp_noise_backward_counter",
            "ddsp_osc_set_tiling", "ddsp_noise_set_generic", "ddsp_profile_enable", "ddsp_profile_read",
            "ddsp_gru_scratch_bytes", "ddsp_gru_max_batch", "ddsp_gru_forward", "ddsp_gru_backward", "ddsp_gru_forward_bf16", "ddsp_gru_backward_bf16", "ddsp_gru_status", "ddsp_gru_set_mode", "ddsp_gru_set_fault_step",
            "ddsp_spectral_loss_scratch_bytes", "ddsp_spectral_loss", "ddsp_scaled_sigmoid_forward", "ddsp_scaled_sigmoid_backward",

@@ -315,6 +315,7 @@ struct NoiseBwdParams {
     int B, T, F, R, S;
     int lpf_log;         // batched kernel: log2(lanes per frame)
     uint64_t seed, offset;
+    const uint64_t *offset_dev;   // nullable: the draw started at offset + *offset_dev (the forward's device counter)
 };
 
 __device__ __forceinline__ float noise_sample(const float *u, long frame, int m, int R, uint64_t seed, uint64_t offset)
@@ -340,7 +341,7 @@ __global__ void __launch_bounds__(256) noise_bwd_frame_kernel(NoiseBwdParams p)
     const int tid = threadIdx.x;
     for (int m = tid; m < S; m += 256) ct[m] = cospif((float)(2 * m) / (float)S);
     for (int m = tid; m < R; m += 256) {
-        x[m] = noise_sample(p.u, frame, m, R, p.seed, p.offset);
+        x[m] = noise_sample(p.u, frame, m, R, p.seed, p.offset + (p.offset_dev ? *p.offset_dev : 0ull));
         g[m] = p.g[frame * R + m];
     }
     for (int n = tid; n <= half; n += 256) Gs[n] = 0.0f;
@@ -402,7 +403,7 @@ __global__ void __launch_bounds__(kNT) noise_bwd_batched_kernel(NoiseBwdParams p
         const int quads = R >> 2;
         for (int e = tid; e < FB * quads; e += kNT) {
             const int f = e / quads, q = e - f * quads;
-            const uint64_t ctr = p.offset + (uint64_t)(frame0 + f) * (uint64_t)quads + (uint64_t)q;
+            const uint64_t ctr = p.offset + (p.offset_dev ? *p.offset_dev : 0ull) + (uint64_t)(frame0 + f) * (uint64_t)quads + (uint64_t)q;
             uint32_t r[4];
             philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r);
             float4 v;
@@ -637,8 +638,24 @@ extern "C" int ddsp_noise_set_generic(int on)
     return 0;
 }
 
+static int noise_backward_impl(const float *grad_y, const float *uniform, float *grad_H, int B, int T, int F, int hop,
+                               uint64_t seed, uint64_t offset, const uint64_t *offset_dev, void *stream);
+
 extern "C" int ddsp_noise_backward(const float *grad_y, const float *uniform, float *grad_H, int B, int T, int F, int hop,
                                    uint64_t seed, uint64_t offset, void *stream)
+{
+    return noise_backward_impl(grad_y, uniform, grad_H, B, T, F, hop, seed, offset, nullptr, stream);
+}
+
+extern "C" int ddsp_noise_backward_counter(const float *grad_y, float *grad_H, int B, int T, int F, int hop, uint64_t seed,
+                                           const uint64_t *counter_dev, void *stream)
+{
+    if (!counter_dev) return DDSP_EINVAL;
+    return noise_backward_impl(grad_y, nullptr, grad_H, B, T, F, hop, seed, 0, counter_dev, stream);
+}
+
+static int noise_backward_impl(const float *grad_y, const float *uniform, float *grad_H, int B, int T, int F, int hop,
+                               uint64_t seed, uint64_t offset, const uint64_t *offset_dev, void *stream)
 {
     if (B == 0) return 0;
     if (!grad_y || !grad_H || B < 0 || T <= 0 || F < 2 || hop <= 0) return DDSP_EINVAL;
@@ -646,7 +663,7 @@ extern "C" int ddsp_noise_backward(const float *grad_y, const float *uniform, fl
     NoiseBwdParams p;
     p.g = grad_y; p.u = uniform; p.gH = grad_H;
     p.B = B; p.T = T; p.F = F; p.R = hop; p.S = 2 * (F - 1);
-    p.seed = seed; p.offset = offset;
+    p.seed = seed; p.offset = offset; p.offset_dev = offset_dev;
     hipStream_t s = (hipStream_t)stream;
     const int lpf_log = pick_bwd_lpf_log(F, hop);
     p.lpf_log = lpf_log < 0 ? 0 : lpf_log;

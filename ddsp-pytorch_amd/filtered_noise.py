@@ -48,8 +48,9 @@ def noise_forward(Hmag, hop: int, uniform=None, seed: int = 0, offset: int = 0, 
     return out
 
 
-def noise_backward(grad_y, hop: int, n_filters: int, uniform=None, seed: int = 0, offset: int = 0):
-    """Raw launcher of ddsp_noise_backward: grad_y [B,T*hop] -> grad_H [B,T,F] for the same draw as the forward."""
+def noise_backward(grad_y, hop: int, n_filters: int, uniform=None, seed: int = 0, offset: int = 0, counter=None):
+    """Raw launcher of ddsp_noise_backward: grad_y [B,T*hop] -> grad_H [B,T,F] for the same draw as the forward
+    (`counter`: the device counter the forward read, still at the same value)."""
     grad_y = grad_y.detach().contiguous().float()
     B = grad_y.shape[0]
     T = grad_y.shape[1] // hop
@@ -58,8 +59,12 @@ def noise_backward(grad_y, hop: int, n_filters: int, uniform=None, seed: int = 0
         return grad_h
     with torch.cuda.device(grad_y.device):
         stream = torch.cuda.current_stream().cuda_stream
-        rc = _lib.lib().ddsp_noise_backward(grad_y.data_ptr(), None if uniform is None else uniform.data_ptr(),
-                                            grad_h.data_ptr(), B, T, n_filters, hop, seed, offset, stream)
+        if counter is not None:
+            rc = _lib.lib().ddsp_noise_backward_counter(grad_y.data_ptr(), grad_h.data_ptr(), B, T, n_filters, hop, seed,
+                                                        counter.data_ptr(), stream)
+        else:
+            rc = _lib.lib().ddsp_noise_backward(grad_y.data_ptr(), None if uniform is None else uniform.data_ptr(),
+                                                grad_h.data_ptr(), B, T, n_filters, hop, seed, offset, stream)
     _lib.check(rc, "ddsp_noise_backward")
     return grad_h
 
@@ -69,11 +74,12 @@ class _NoiseFunction(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, Hmag, uniform, hop, seed, offset):
+    def forward(ctx, Hmag, uniform, hop, seed, offset, counter=None):
         if uniform is not None:
             uniform = uniform.detach().to(device=Hmag.device, dtype=torch.float32).contiguous()
-        y = noise_forward(Hmag, hop, uniform=uniform, seed=seed, offset=offset)
+        y = noise_forward(Hmag, hop, uniform=uniform, seed=seed, offset=offset, counter=counter)
         ctx.save_for_backward(uniform)
+        ctx.counter = counter        # read again by the backward: the owner advances it only after that (GraphedTrainStep)
         ctx.meta = (hop, Hmag.shape[-1], seed, offset)
         return y
 
@@ -82,7 +88,7 @@ class _NoiseFunction(torch.autograd.Function):
     def backward(ctx, grad_y):
         (uniform,) = ctx.saved_tensors
         hop, nf, seed, offset = ctx.meta
-        return noise_backward(grad_y, hop, nf, uniform=uniform, seed=seed, offset=offset), None, None, None, None
+        return noise_backward(grad_y, hop, nf, uniform=uniform, seed=seed, offset=offset, counter=ctx.counter), None, None, None, None, None
 
 
 class FilteredNoise(nn.Module):
@@ -97,6 +103,9 @@ class FilteredNoise(nn.Module):
         # calls of different shapes (a last partial batch, train/eval switches) never overlap earlier draws.  Not part of
         # the state_dict (the reference has no such state): a resumed run that must not replay the stream passes a new `seed`.
         self._offset = 0
+        # hipGraph-captured training steps (graphed.GraphedTrainStep): the offset lives in this 1-element int64 CUDA tensor, read by
+        # the forward AND the backward kernel at run time and advanced by a node of the graph after both
+        self.counter = None
 
     def reseed(self, seed: int, offset: int = 0) -> None:
         """Restart the in-kernel (rng='device') stream: a resumed training run passes a fresh seed (or the offset it saved)
@@ -109,13 +118,21 @@ class FilteredNoise(nn.Module):
         B, T, _ = param.shape
         if noise is None and self.rng == 'host':
             noise = torch.rand(B, T, self.block_size)  # :44-48: CPU global generator, same shape and order
-        offset = 0
+        offset, counter = 0, None
         if noise is None:
-            offset = self._offset
-            self._offset += B * T * ((self.block_size + 3) // 4)
+            if self.counter is not None:
+                counter = self.counter
+                self._last_draws = self.draws(B, T)     # what the owner of the counter adds after the backward
+            else:
+                offset = self._offset
+                self._offset += self.draws(B, T)
         if torch.is_grad_enabled() and param.requires_grad:
             if not param.is_cuda:
                 raise _lib.DdspHipError("FilteredNoise runs on the GPU only (no CPU fallback): move the controls to cuda")
-            return _NoiseFunction.apply(param, noise, self.block_size, self.seed, offset)
+            return _NoiseFunction.apply(param, noise, self.block_size, self.seed, offset, counter)
         return noise_forward(param, self.block_size, uniform=noise, seed=self.seed, offset=offset, out=out,
-                             accumulate=out is not None)
+                             accumulate=out is not None, counter=counter)
+
+    def draws(self, batch: int, frames: int) -> int:
+        """Philox counters one in-kernel draw of this shape consumes."""
+        return batch * frames * ((self.block_size + 3) // 4)

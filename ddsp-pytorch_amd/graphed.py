@@ -13,7 +13,8 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from .filtered_noise import noise_forward
+from . import dense
+from .filtered_noise import FilteredNoise, noise_forward
 from .harmonic_oscillator import osc_forward
 
 
@@ -148,3 +149,127 @@ class GraphedLiveDecoder:
             buf.copy_(v if torch.is_tensor(v) else torch.from_numpy(v), non_blocking=True)
         self._graph.replay()
         return self.out.cpu().squeeze(0).numpy()
+
+
+class GraphedTrainStep:
+    """`training.train_step` for a FIXED batch shape as hipGraph replays: forward, spectral loss, backward and the optimiser
+    update of one step are captured once (about 280 launches at the training shape, whose host-side issue time had become as
+    long as the GPU's work); a step is then the copies of the batch into the static input tensors and one replay (with more
+    than one rank: replay forward + backward, ONE eager flat all-reduce, replay the update).
+
+    * `optimizer` must be capturable (`torch.optim.Adam(..., capturable=True)`; `fused=True` as well if wanted).
+    * Constructing the object does not advance training: the warm-up steps capture needs (library handles, FFT plans,
+      allocator pools, optimiser state) are undone -- parameters, buffers and optimiser state are put back in place; state the
+      optimiser did not have yet is zeroed, which is what Adam-style optimisers start from.
+    * A `FilteredNoise(rng='device')` inside the model draws from a device-resident Philox counter from here on (read by the
+      forward and the backward kernel, advanced by a node of the graph): every replay gets fresh noise, the same sequence as
+      the eager steps.
+    * fp32 or `amp_dtype=torch.bfloat16` (no GradScaler: fp16 needs its host-side decisions); every rank must hold rows.
+    * The persistent GRU launches inside a graph are ordered by the graph only: do not run another recurrence on a second
+      stream of the same device while a replay is in flight (DESIGN.md par. 9a).
+    """
+
+    def __init__(self, model, loss_fn, optimizer, example_batch, group=None, amp_dtype=None, warmup: int = 3):
+        import torch.distributed as dist
+        self.model, self.loss_fn, self.opt, self.group, self.amp_dtype = model, loss_fn, optimizer, group, amp_dtype
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if not self.params or not self.params[0].is_cuda:
+            raise _lib.DdspHipError("GraphedTrainStep needs the model on a GPU")
+        if not all(g.get("capturable", False) for g in optimizer.param_groups):
+            raise ValueError("GraphedTrainStep needs a capturable optimiser, e.g. torch.optim.Adam(params, capturable=True)")
+        dev = self.params[0].device
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.batch = {k: (v.detach().to(dev).clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
+        if next((v.shape[0] for v in self.batch.values() if torch.is_tensor(v)), 0) == 0:
+            raise ValueError("GraphedTrainStep cannot capture an empty shard")
+        self.noises = [m for m in model.modules() if isinstance(m, FilteredNoise) and m.rng == "device"]
+        # (the modules see their counter only inside this object's steps; eager calls keep the host-side offset)
+        self.counters = [torch.tensor([m._offset], dtype=torch.int64, device=dev) for m in self.noises]
+        self.loss = None
+        self.nbytes = sum(p.numel() * p.element_size() for p in self.params)
+        self._capture(dev, warmup)
+
+    # one step in two halves (a collective sits between them when there is more than one rank)
+    def _forward_backward(self):
+        for m, c in zip(self.noises, self.counters):
+            m.counter = c
+        try:
+            if self.amp_dtype is not None:
+                dense.lowp_weights.refresh(self.amp_dtype)
+            with torch.autocast("cuda", dtype=self.amp_dtype or torch.bfloat16, enabled=self.amp_dtype is not None):
+                audio = self.model(self.batch)
+            loss = self.loss_fn(audio.float(), self.batch)
+            loss.backward()
+            for m, c in zip(self.noises, self.counters):
+                c.add_(m._last_draws)
+        finally:
+            for m in self.noises:
+                m.counter = None
+        return loss.detach()
+
+    def _reduce(self):
+        import torch.distributed as dist
+        grads = [p.grad for p in self.params]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat /= self.world
+        torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+
+    def _capture(self, dev, warmup):
+        model_state = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        had = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in self.opt.state.get(p, {}).items()}
+               for g in self.opt.param_groups for p in g["params"]}
+        counters = [c.clone() for c in self.counters]
+
+        def restore():
+            with torch.no_grad():
+                live = self.model.state_dict()
+                for k, v in model_state.items():
+                    live[k].copy_(v)
+                for g in self.opt.param_groups:
+                    for p in g["params"]:
+                        for k, v in self.opt.state.get(p, {}).items():
+                            if torch.is_tensor(v):
+                                old = had[id(p)].get(k)
+                                v.copy_(old) if old is not None else v.zero_()
+                for live_c, c in zip(self.counters, counters):
+                    live_c.copy_(c)
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self.opt.zero_grad(set_to_none=True)
+                self._forward_backward()
+                if self.world > 1:
+                    self._reduce()
+                self.opt.step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        restore()
+        self.opt.zero_grad(set_to_none=True)          # the captured backward allocates the gradients inside the graph's pool
+        self._graph = torch.cuda.CUDAGraph()
+        self._graph_update = None
+        with torch.cuda.graph(self._graph):
+            self.loss = self._forward_backward()
+            if self.world == 1:
+                self.opt.step()
+        if self.world > 1:
+            self._graph_update = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_update, pool=self._graph.pool()):
+                self.opt.step()
+        restore()
+
+    def step(self, batch=None):
+        """One optimisation step on `batch` (same keys and shapes as the example; None = whatever the static inputs hold).
+        Returns (loss tensor -- static, overwritten by the next step --, all-reduce bytes)."""
+        if batch is not None:
+            for k, v in batch.items():
+                if torch.is_tensor(v):
+                    self.batch[k].copy_(v, non_blocking=True)
+        self._graph.replay()
+        if self.world > 1:
+            self._reduce()
+            self._graph_update.replay()
+        return self.loss, self.nbytes
+
+    __call__ = step

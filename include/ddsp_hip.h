@@ -92,6 +92,10 @@ int ddsp_osc_backward(const float *grad_y, const float *f0, const float *c, cons
  */
 int ddsp_noise_backward(const float *grad_y, const float *uniform, float *grad_H, int B, int T, int F, int hop,
                         uint64_t seed, uint64_t offset, void *stream);
+/* The backward of a ddsp_noise_forward_counter call: the same draw, read from the same device counter (which the caller
+ * advances only after both). */
+int ddsp_noise_backward_counter(const float *grad_y, float *grad_H, int B, int T, int F, int hop, uint64_t seed,
+                                const uint64_t *counter_dev, void *stream);
 
 /*
  * Tuning hook (benchmarks only): force the number of harmonics each lane keeps in registers

@@ -602,3 +602,40 @@ def test_lowp_weight_copies_are_never_stale():
     cache.refresh(torch.bfloat16)
     assert torch.equal(cache.get(w, torch.bfloat16), w.detach().bfloat16())
     assert cache.get(w, torch.float16) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("amp_dtype", [None, torch.bfloat16])
+def test_graphed_train_step_equals_eager_steps(amp_dtype):
+    """GraphedTrainStep (forward, MSS loss, backward, Adam captured as one hipGraph) against eager train_step from the same
+    start: same losses and parameters after four steps on changing batches -- construction must not advance training (warm-up
+    undone), and the in-kernel noise must move on from replay to replay exactly as the eager steps' host-side offset does."""
+    class Conf:
+        n_harmonics, n_noise_filters, sample_rate, hop_length = 16, 9, 4000, 16
+        decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 256, 2, 64, 1
+
+    def make():
+        torch.manual_seed(11)
+        model = ddsp.Decoder(Conf, noise_rng="device", seed=3).cuda()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+        return model, ddsp.MSSLoss((256, 128, 64)).cuda(), opt
+
+    def batch(i, B=3, T=40):
+        g = torch.Generator().manual_seed(100 + i)
+        return {"normalized_cents": torch.rand(B, T, 1, generator=g).cuda(), "loudness": (torch.rand(B, T, 1, generator=g) * 2 - 1).cuda(),
+                "f0": (100 + 200 * torch.rand(B, T, 1, generator=g)).cuda(), "audio": (0.1 * torch.randn(B, T * 16, generator=g)).cuda()}
+
+    m_e, l_e, o_e = make()
+    m_g, l_g, o_g = make()
+    graphed = ddsp.GraphedTrainStep(m_g, l_g, o_g, batch(0), amp_dtype=amp_dtype)
+    for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+        assert torch.equal(a, b), k                                    # construction left the model where it was
+    tol = 2e-2 if amp_dtype is not None else 1e-4
+    for i in range(4):
+        loss_e, nbytes_e = ddsp.train_step(m_e, l_e, o_e, batch(i), amp_dtype=amp_dtype)
+        loss_g, nbytes_g = graphed.step(batch(i))
+        assert nbytes_e == nbytes_g
+        assert abs(loss_e.item() - loss_g.item()) <= tol * abs(loss_e.item()), (i, loss_e.item(), loss_g.item())
+    for (k, a), (_, b) in zip(m_e.named_parameters(), m_g.named_parameters()):
+        assert float((a - b).abs().max()) <= tol * max(1e-3, float(a.abs().max())), k
+    assert m_g.noise.counter is None and int(graphed.counters[0].item()) == 4 * m_g.noise.draws(3, 40) == m_e.noise._offset
