@@ -106,6 +106,7 @@ class FilteredNoise(nn.Module):
         # hipGraph-captured training steps (graphed.GraphedTrainStep): the offset lives in this 1-element int64 CUDA tensor, read by
         # the forward AND the backward kernel at run time and advanced by a node of the graph after both
         self.counter = None
+        self._last_draws = 0
 
     def reseed(self, seed: int, offset: int = 0) -> None:
         """Restart the in-kernel (rng='device') stream: a resumed training run passes a fresh seed (or the offset it saved)

@@ -175,7 +175,7 @@ class GraphedTrainStep:
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params or not self.params[0].is_cuda:
             raise _lib.DdspHipError("GraphedTrainStep needs the model on a GPU")
-        if not all(g.get("capturable", False) for g in optimizer.param_groups):
+        if not all(g.get("capturable", True) for g in optimizer.param_groups):     # (optimisers without the option, e.g. SGD, never synchronise)
             raise ValueError("GraphedTrainStep needs a capturable optimiser, e.g. torch.optim.Adam(params, capturable=True)")
         dev = self.params[0].device
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -192,7 +192,7 @@ class GraphedTrainStep:
     # one step in two halves (a collective sits between them when there is more than one rank)
     def _forward_backward(self):
         for m, c in zip(self.noises, self.counters):
-            m.counter = c
+            m.counter, m._last_draws = c, 0
         try:
             if self.amp_dtype is not None:
                 dense.lowp_weights.refresh(self.amp_dtype)
@@ -201,7 +201,8 @@ class GraphedTrainStep:
             loss = self.loss_fn(audio.float(), self.batch)
             loss.backward()
             for m, c in zip(self.noises, self.counters):
-                c.add_(m._last_draws)
+                if m._last_draws:                      # (0: the caller injected its own draw, the counter was not read)
+                    c.add_(m._last_draws)
         finally:
             for m in self.noises:
                 m.counter = None

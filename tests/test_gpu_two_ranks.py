@@ -91,6 +91,18 @@ def test_data_parallel_replicas_lock_step_and_equal_single_process(rank_outputs)
     assert abs(0.5 * float(l0[0] + l1[0]) - losses[0]) <= 1e-4 * abs(losses[0])
 
 
+def test_graphed_data_parallel_steps_equal_eager_ones(rank_outputs):
+    """GraphedTrainStep on two ranks (forward + backward graph, one eager flat all-reduce, update graph) ends where the eager
+    data-parallel steps end, on both ranks."""
+    sd = torch.load(rank_outputs / "sd0.pt", weights_only=True)
+    g0 = torch.load(rank_outputs / "sdg0.pt", weights_only=True)
+    g1 = torch.load(rank_outputs / "sdg1.pt", weights_only=True)
+    assert all(torch.equal(g0[k], g1[k]) for k in g0)
+    for k in sd:
+        if sd[k].dtype.is_floating_point:
+            assert float((g0[k] - sd[k]).abs().max()) <= 1e-6 * max(1e-3, float(sd[k].abs().max())), k
+
+
 def test_bench_self_launches_two_ranks():
     """bench.py --gpus 2 with no WORLD_SIZE: the parent (GPU-free) starts two ranks under torch.distributed.run, both on
     this box's one GPU (--one-device, gloo), small batch; rank 0 prints the one JSON line."""

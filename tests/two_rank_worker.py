@@ -6,7 +6,7 @@ argv: out_dir
   1. batch-sharded synthesis (BASELINE.json configs[3]): this rank's contiguous rows of one global batch
      through OscillatorBank + FilteredNoise -> y{rank}.pt (the parent compares the concatenation with the unsharded run)
   2. data-parallel training step (configs[4]): identical replicas, this rank's half of the batch, ONE flat all-reduce
-     of the gradients through `train_step` -> sd{rank}.pt, gru{rank}.pt
+     of the gradients through `train_step` -> sd{rank}.pt; the same through `GraphedTrainStep` -> sdg{rank}.pt
 """
 import os
 import sys
@@ -53,6 +53,14 @@ def main():
     torch.cuda.synchronize()
     torch.save({k: v.cpu() for k, v in model.state_dict().items()}, os.path.join(out_dir, f"sd{rank}.pt"))
     torch.save(torch.tensor(losses), os.path.join(out_dir, f"loss{rank}.pt"))
+
+    # ---- 3. the same steps as hipGraph replays (GraphedTrainStep: graph, ONE eager all-reduce, graph) ---------------
+    model_g, loss_g, opt_g = common.make_trainer(ddsp)
+    graphed = ddsp.GraphedTrainStep(model_g, loss_g, opt_g, shard)
+    for _ in range(common.TRAIN_STEPS):
+        graphed.step(shard)
+    torch.cuda.synchronize()
+    torch.save({k: v.cpu() for k, v in model_g.state_dict().items()}, os.path.join(out_dir, f"sdg{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
