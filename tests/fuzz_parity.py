@@ -66,6 +66,67 @@ def sweep(cases: int, seed: int, verbose: bool = True):
     return bad, worst_osc, worst_noise
 
 
+def sweep_training_kernels(cases: int, seed: int, verbose: bool = True):
+    """Random shapes of the loss-side kernels against torch on the CPU in fp64: ddsp_mss_scale (+ the overlap-add gather) for random
+    batch / length / transform size / overlap, the framing pair around a library rfft, and the column sums.  -> failed cases"""
+    from ddsp_pytorch_amd import dense
+    from ddsp_pytorch_amd.training import SpectralLoss
+    rng = np.random.default_rng(seed)
+    g = torch.Generator().manual_seed(seed)
+    bad = 0
+    for i in range(cases):
+        n_fft = int(rng.choice([64, 128, 256, 512, 1024, 2048]))
+        overlap = float(rng.choice([0.75, 0.75, 0.5, 0.875, 0.0]))
+        B = int(rng.integers(1, 6))
+        L = int(rng.integers(n_fft // 2 + 1, n_fft // 2 + 1 + int(rng.choice([3, 200, 5000]))))
+        x_true = 0.3 * torch.randn(B, L, generator=g)
+        x_pred = 0.3 * torch.randn(B, L, generator=g)
+        if rng.random() < 0.3:
+            x_true[0, : L // 2] = 0.0
+        sl = SpectralLoss(n_fft, alpha=float(rng.choice([1.0, 0.3])), overlap=overlap)
+        xp = x_pred.double().requires_grad_(True)
+        ref = sl.double()(xp, x_true.double())
+        ref.backward()
+        sl_gpu = SpectralLoss(n_fft, alpha=sl.alpha, overlap=overlap).cuda()
+        xg = x_pred.cuda().requires_grad_(True)
+        fused = sl_gpu.fused_scale(xg) is not None
+        got = sl_gpu(xg, x_true.cuda())
+        got.backward()
+        e_loss = abs(got.item() - ref.item()) / abs(ref.item())
+        gd = xg.grad.cpu().double() - xp.grad
+        e_l2 = float(gd.norm() / xp.grad.norm())
+        e_max = float(gd.abs().max() / xp.grad.abs().max())
+        # the yardstick: what fp32 arithmetic does to this gradient in the torch formulation itself (the log term goes like
+        # 1 / (|S|^2 + eps) per bin: one near-empty bin of the prediction and any fp32 transform is off by 1e-3 of the norm)
+        x32 = x_pred.clone().requires_grad_(True)
+        SpectralLoss(n_fft, alpha=sl.alpha, overlap=overlap)(x32, x_true).backward()
+        d32 = x32.grad.double() - xp.grad
+        y_l2, y_max = float(d32.norm() / xp.grad.norm()), float(d32.abs().max() / xp.grad.abs().max())
+        # framing pair (+ library rfft) against torch.stft, value and gradient
+        xa = x_pred.cuda().requires_grad_(True)
+        xb = x_pred.cuda().requires_grad_(True)
+        fa = sl_gpu.stft_ri(xa)
+        fb = torch.view_as_real(sl_gpu.stft(xb)).transpose(1, 2)
+        w = torch.randn(fa.shape, generator=g).cuda()
+        (fa * w).sum().backward()
+        (fb * w).sum().backward()
+        e_fr = float((fa - fb).abs().max() / fb.abs().max())
+        e_frg = float((xa.grad - xb.grad).abs().max() / xb.grad.abs().max())
+        # column sums
+        M, N = int(rng.integers(0, 20000)), int(rng.integers(1, 1600))
+        dt = [torch.float32, torch.bfloat16, torch.float16][int(rng.integers(0, 3))]
+        xm = torch.randn(M, N, generator=g).cuda().to(dt)
+        e_cs = float((dense.colsum(xm).double() - xm.double().sum(0)).abs().max()) / max(1.0, float(xm.double().abs().sum(0).max())) if M else \
+            float(dense.colsum(xm).abs().max())
+        okay = (fused and e_loss <= 2e-5 and e_l2 <= max(5e-4, 4.0 * y_l2) and e_max <= max(2e-3, 4.0 * y_max)
+                and e_fr <= 3e-6 and e_frg <= 3e-6 and e_cs <= 2e-6)
+        bad += not okay
+        if verbose or not okay:
+            print(f"{'ok ' if okay else 'BAD'} case {i}: n_fft {n_fft} overlap {overlap} B {B} L {L} | loss {e_loss:.1e} grad L2 {e_l2:.1e} (fp32 torch {y_l2:.1e}) max {e_max:.1e} ({y_max:.1e}) | "
+                  f"frames {e_fr:.1e} grad {e_frg:.1e} | colsum [{M},{N}] {str(dt)[6:]} {e_cs:.1e}")
+    return bad
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026

@@ -11,3 +11,9 @@ import fuzz_parity  # noqa: E402
 def test_random_shapes_match_the_oracle(seed):
     bad, worst_audio, worst_noise = fuzz_parity.sweep(50, seed, verbose=False)
     assert bad == 0, (bad, worst_audio, worst_noise)
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_shapes_of_the_loss_side_kernels_match_torch(seed):
+    """40 random cases per seed: one-kernel spectral-loss scales (value + gradient, any overlap), the framing pair, column sums."""
+    assert fuzz_parity.sweep_training_kernels(40, seed, verbose=False) == 0
