@@ -152,8 +152,10 @@ def train_mode(args, rank, world, dist):
         def one_step():
             return graphed.step()
     else:
+        reducer = ddsp.OverlappedGradientReducer(model.parameters()) if (args.overlap_allreduce and world > 1) else None
+
         def one_step():
-            return ddsp.train_step(model, loss_fn, opt, batch, amp_dtype=amp_dtype, scaler=scaler)
+            return ddsp.train_step(model, loss_fn, opt, batch, amp_dtype=amp_dtype, scaler=scaler, reducer=reducer)
     for _ in range(args.warmup):
         _, nbytes = one_step()
     fence()
@@ -176,7 +178,8 @@ def train_mode(args, rank, world, dist):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.amp == "none" else f"{args.amp} GEMMs (autocast), f32 synthesis / loss / optimiser", "data": "synthetic",
             "config": {"workload": f"decoder (4.84 M params) + HIP synth + reverb + MSS loss (6 scales) + Adam, batch {b}/GPU, "
-                                   f"16 kHz, 100 harmonics, 65 noise bands, 4 s", "parallelism": f"dp{world}, one flat all-reduce" + (", step captured as a hipGraph" if args.graph else ""),
+                                   f"16 kHz, 100 harmonics, 65 noise bands, 4 s", "parallelism": f"dp{world}, " + ("bucketed all-reduces overlapping the backward" if (args.overlap_allreduce and world > 1 and not args.graph)
+                                                          else "one flat all-reduce") + (", step captured as a hipGraph" if args.graph else ""),
                        "allreduce_bytes": nbytes},
             "final_loss": float(loss)}), flush=True)
     if dist is not None:
@@ -200,6 +203,9 @@ def main():
     ap.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"],
                     help="train mode: autocast dtype of the dense layers' GEMMs (reference: precision=16, train/train.py:50); "
                          "off by default, the synthesis kernels stay fp32 either way")
+    ap.add_argument("--overlap-allreduce", action="store_true",
+                    help="train mode, N > 1: bucketed gradient all-reduces that start during the backward (OverlappedGradientReducer) "
+                         "instead of one flat all-reduce after it")
     ap.add_argument("--graph", action="store_true",
                     help="train mode: capture the whole step (forward, loss, backward, Adam) as hipGraph replays (GraphedTrainStep)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

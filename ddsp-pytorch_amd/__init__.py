@@ -15,7 +15,7 @@ from .reverb import Reverb, causal_fft_convolve  # noqa: F401
 from .graphed import GraphedSynth, GraphedLiveDecoder, GraphedTrainStep  # noqa: F401
 from .gru import GRU, gru_forward, gru_backward, gru_status  # noqa: F401
 from .decoder import Controller, Decoder  # noqa: F401
-from .training import MSSLoss, train_step, allreduce_gradients  # noqa: F401
+from .training import MSSLoss, train_step, allreduce_gradients, OverlappedGradientReducer  # noqa: F401
 
-__all__ = ["OscillatorBank", "FilteredNoise", "Reverb", "causal_fft_convolve", "GraphedSynth", "GraphedLiveDecoder", "GraphedTrainStep", "Controller", "Decoder", "GRU", "MSSLoss", "train_step", "allreduce_gradients", "osc_forward", "osc_backward", "noise_forward", "noise_backward",
+__all__ = ["OscillatorBank", "FilteredNoise", "Reverb", "causal_fft_convolve", "GraphedSynth", "GraphedLiveDecoder", "GraphedTrainStep", "Controller", "Decoder", "GRU", "MSSLoss", "train_step", "allreduce_gradients", "OverlappedGradientReducer", "osc_forward", "osc_backward", "noise_forward", "noise_backward",
            "synthetic"]

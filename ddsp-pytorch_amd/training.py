@@ -220,8 +220,95 @@ def allreduce_gradients(params, group=None) -> int:
     return nbytes
 
 
+class OverlappedGradientReducer:
+    """The gradient average of a data-parallel step in a few buckets whose all-reduces start DURING the backward.
+
+    `train_step`'s default is one flat all-reduce after the backward (19 MB for the 16 kHz / 100 / 65 decoder): simplest, one
+    collective, but the xGMI ring then sits on the critical path of every step.  The control network's gradients become final
+    in a fixed order -- heads, the `mlp_gru` stack, the recurrence (whose backward alone is 1.3 ms at the training shape), the two
+    input stacks -- so the buckets (parameters in reverse registration order, `bucket_bytes` each) are reduced while the rest of
+    the backward still runs: a post-accumulate hook copies each finished gradient into its bucket's flat buffer and the hook of
+    the bucket's last gradient starts `all_reduce(async_op=True)` (RCCL runs it on its own stream behind the copies).
+    `finish()` waits for the collectives, averages, and leaves every `p.grad` a view into its bucket.  Parameters that got no
+    gradient (or a rank that ran no backward at all: an empty shard) contribute zeros, so the ranks always issue the same
+    collectives in the same order.  Correctness is covered by two-rank tests (gloo on the CPU, two processes on one GPU); the
+    gain needs more than one physical GPU and is **unmeasured** here.
+    """
+
+    def __init__(self, params, group=None, bucket_bytes: int = 8 << 20):
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = []                       # [flat buffer, [(param, offset, numel)], pending count, work]
+        self.where = {}
+        order = list(reversed(self.params))
+        i = 0
+        while i < len(order):
+            members, size = [], 0
+            while i < len(order) and (not members or (size + order[i].numel()) * order[i].element_size() <= bucket_bytes) \
+                    and (not members or order[i].dtype == members[0][0].dtype and order[i].device == members[0][0].device):
+                members.append((order[i], size, order[i].numel()))
+                size += order[i].numel()
+                i += 1
+            flat = torch.zeros(size, dtype=members[0][0].dtype, device=members[0][0].device)
+            self.buckets.append([flat, members, len(members), None])
+            for p, off, n in members:
+                self.where[id(p)] = (len(self.buckets) - 1, off, n)
+        self.arrived = set()
+        self.next = 0                           # first bucket whose collective has not started yet
+        self.handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params] if self.world > 1 else []
+        self.nbytes = sum(p.numel() * p.element_size() for p in self.params)
+
+    def _launch_ready(self):
+        """Collectives start in BUCKET ORDER on every rank, whatever order the gradients arrive in (a rank without rows issues
+        them all from `finish`): a finished bucket waits for the ones before it."""
+        import torch.distributed as dist
+        while self.next < len(self.buckets) and self.buckets[self.next][2] == 0:
+            bucket = self.buckets[self.next]
+            bucket[3] = dist.all_reduce(bucket[0], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.next += 1
+
+    def _hook(self, p):
+        b, off, n = self.where[id(p)]
+        bucket = self.buckets[b]
+        bucket[0][off:off + n].copy_(p.grad.reshape(-1))
+        self.arrived.add(id(p))
+        bucket[2] -= 1
+        self._launch_ready()
+
+    def finish(self) -> int:
+        """After the backward (or instead of one): complete every bucket, average, point the gradients into the buckets."""
+        if self.world > 1:
+            for flat, members, _, work in self.buckets[self.next:]:      # gradients that never arrived on this rank: zeros
+                for p, off, n in members:
+                    if id(p) not in self.arrived:
+                        if p.grad is not None:
+                            flat[off:off + n].copy_(p.grad.reshape(-1))
+                        else:
+                            flat[off:off + n].zero_()
+            for bucket in self.buckets[self.next:]:
+                bucket[2] = 0
+            self._launch_ready()
+            for bucket in self.buckets:
+                flat, members, _, work = bucket
+                work.wait()
+                flat /= self.world
+                for p, off, n in members:
+                    p.grad = flat[off:off + n].view_as(p)
+                bucket[2], bucket[3] = len(members), None
+            self.arrived.clear()
+            self.next = 0
+        return self.nbytes
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []
+
+
 def train_step(model: nn.Module, loss_fn: nn.Module, optimizer: torch.optim.Optimizer, batch, group=None, amp_dtype=None,
-               scaler=None):
+               scaler=None, reducer: "OverlappedGradientReducer | None" = None):
     """One optimisation step of `Zak.training_step` (train/train.py:32-37) + Adam, data-parallel.
     `batch` is this rank's shard: a dict with the controller inputs and the target `audio`.
     `amp_dtype` (torch.bfloat16 / torch.float16; default None = fp32 everywhere): the reference trains with
@@ -246,7 +333,10 @@ def train_step(model: nn.Module, loss_fn: nn.Module, optimizer: torch.optim.Opti
             audio = model(batch)
         loss = loss_fn(audio.float(), batch)
         (scaler.scale(loss) if scaler is not None else loss).backward()
-    nbytes = allreduce_gradients([p for p in model.parameters() if p.requires_grad], group)
+    if reducer is not None:
+        nbytes = reducer.finish()
+    else:
+        nbytes = allreduce_gradients([p for p in model.parameters() if p.requires_grad], group)
     if scaler is not None:
         scaler.step(optimizer)     # unscales, skips the step on inf / nan (the averaged gradients are still scaled here)
         scaler.update()

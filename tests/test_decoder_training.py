@@ -109,6 +109,19 @@ def _ddp_worker(rank, world, port, out_dir):
     loss, nbytes = ddsp.train_step(model, ddsp.MSSLoss((128, 64)), opt, shard)
     assert nbytes == 4 * sum(p.numel() for p in model.parameters())
     torch.save({k: v for k, v in model.state_dict().items()}, os.path.join(out_dir, f"sd{rank}.pt"))
+    # the same two steps with the bucketed reducer whose all-reduces start during the backward (small buckets: several of them,
+    # finishing out of registration order), the second step with rank 1 holding NO rows
+    torch.manual_seed(5)
+    model_b = CpuSurrogate()
+    opt_b = torch.optim.Adam(model_b.parameters(), lr=1e-3)
+    reducer = ddsp.OverlappedGradientReducer(model_b.parameters(), bucket_bytes=4 << 10)
+    assert len(reducer.buckets) >= 3
+    loss_b, nbytes_b = ddsp.train_step(model_b, ddsp.MSSLoss((128, 64)), opt_b, shard, reducer=reducer)
+    assert nbytes_b == nbytes and abs(float(loss_b) - float(loss)) <= 1e-6 * abs(float(loss))
+    torch.save({k: v for k, v in model_b.state_dict().items()}, os.path.join(out_dir, f"sdb{rank}.pt"))
+    lo2, hi2 = (0, 3) if rank == 0 else (3, 3)
+    ddsp.train_step(model_b, ddsp.MSSLoss((128, 64)), opt_b, {k: v[lo2:hi2] for k, v in full.items()}, reducer=reducer)
+    torch.save({k: v for k, v in model_b.state_dict().items()}, os.path.join(out_dir, f"sdb2_{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -124,6 +137,15 @@ def test_data_parallel_step_two_ranks_equals_single(tmp_path):
     ref = model.state_dict()
     # mean-reduced loss: averaging equal-size shards' gradients == the global-batch gradient
     assert max(float((ref[k] - sd0[k]).abs().max()) for k in ref) <= 2e-5
+    # bucketed, overlapped reduction: the same update as the flat all-reduce; replicas stay in lock-step also when one rank has no rows
+    sdb0 = torch.load(tmp_path / "sdb0.pt", weights_only=True)
+    sdb1 = torch.load(tmp_path / "sdb1.pt", weights_only=True)
+    assert all(torch.equal(sdb0[k], sdb1[k]) for k in sdb0)
+    assert max(float((sdb0[k] - sd0[k]).abs().max()) for k in sd0) <= 1e-7
+    e0 = torch.load(tmp_path / "sdb2_0.pt", weights_only=True)
+    e1 = torch.load(tmp_path / "sdb2_1.pt", weights_only=True)
+    assert all(torch.equal(e0[k], e1[k]) for k in e0)
+    assert any(not torch.equal(e0[k], sdb0[k]) for k in e0)
 
 
 def test_train_step_with_an_empty_shard():

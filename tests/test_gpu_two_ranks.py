@@ -103,6 +103,17 @@ def test_graphed_data_parallel_steps_equal_eager_ones(rank_outputs):
             assert float((g0[k] - sd[k]).abs().max()) <= 1e-6 * max(1e-3, float(sd[k].abs().max())), k
 
 
+def test_overlapped_bucketed_reduction_equals_the_flat_one(rank_outputs):
+    """OverlappedGradientReducer (buckets all-reduced while the backward still runs) on two ranks of the HIP path."""
+    sd = torch.load(rank_outputs / "sd0.pt", weights_only=True)
+    o0 = torch.load(rank_outputs / "sdo0.pt", weights_only=True)
+    o1 = torch.load(rank_outputs / "sdo1.pt", weights_only=True)
+    assert all(torch.equal(o0[k], o1[k]) for k in o0)
+    for k in sd:
+        if sd[k].dtype.is_floating_point:
+            assert float((o0[k] - sd[k]).abs().max()) <= 1e-6 * max(1e-3, float(sd[k].abs().max())), k
+
+
 def test_bench_self_launches_two_ranks():
     """bench.py --gpus 2 with no WORLD_SIZE: the parent (GPU-free) starts two ranks under torch.distributed.run, both on
     this box's one GPU (--one-device, gloo), small batch; rank 0 prints the one JSON line."""

@@ -61,6 +61,15 @@ def main():
         graphed.step(shard)
     torch.cuda.synchronize()
     torch.save({k: v.cpu() for k, v in model_g.state_dict().items()}, os.path.join(out_dir, f"sdg{rank}.pt"))
+
+    # ---- 4. the same steps with the bucketed reducer whose all-reduces start during the backward ---------------------
+    model_o, loss_o, opt_o = common.make_trainer(ddsp)
+    reducer = ddsp.OverlappedGradientReducer(model_o.parameters(), bucket_bytes=16 << 10)
+    assert len(reducer.buckets) >= 3
+    for _ in range(common.TRAIN_STEPS):
+        ddsp.train_step(model_o, loss_o, opt_o, shard, reducer=reducer)
+    torch.cuda.synchronize()
+    torch.save({k: v.cpu() for k, v in model_o.state_dict().items()}, os.path.join(out_dir, f"sdo{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
