@@ -179,7 +179,9 @@ __device__ __forceinline__ void publish3(gu64 *dst, unsigned epoch, float v0, fl
 }
 
 // (Tried on top, same-process A/B at 512 units: the backward WITHOUT first light 2.72 -> 3.05 us per step at batch 32, and two sets of polls
-//  in flight half a round trip apart 1.83 -> 2.24 forward / 2.72 -> 3.29 backward -- every extra poll slows the L2 for the publishers.)
+//  in flight half a round trip apart 1.83 -> 2.24 forward / 2.72 -> 3.29 backward -- every extra poll slows the L2 for the publishers;
+//  first light on ONE granule per publisher instead of one per column: polled by every wavefront 2.65 -> 3.0, polled by wavefront 0 alone
+//  + a barrier 2.65 -> 2.66 at batch 32 (2.31 -> 2.05 at batch 8): not taken.)
 // sweep_rows for packed granules: `rows` granule rows of width Hd (stride HP); PACK values of each granule go to the bf16 LDS image at
 // dst[(row * PACK + i) * DS + column] (PACK2: image rows 2r, 2r+1 = batch rows; PACK3: image rows 3r + gate).
 template <int RB, bool FIRST_LIGHT, int PACK>
