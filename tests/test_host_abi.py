@@ -60,6 +60,16 @@ def test_argument_validation_without_gpu():
     assert L.ddsp_ln_lrelu_scratch_bytes(512) > 0
     assert L.ddsp_ln_lrelu_backward(None, None, None, None, None, None, None, None, None, None, 0, 512, 0.01, None) == -1   # empty rows still need dgamma/dbeta
     assert L.ddsp_gru_set_fault_step(-1) == -2 and L.ddsp_gru_set_fault_step(0) == 0
+    # round-2 entry points: framing, one-kernel loss scale, column sums, reverb, counter-driven noise backward
+    assert L.ddsp_stft_frames(None, None, None, 1, 4096, 512, 128, None) == -1 and L.ddsp_stft_frames(None, None, None, 0, 4096, 512, 128, None) == 0
+    assert L.ddsp_stft_frames_backward(None, None, None, 1, 4096, 512, 128, 0, None) == -1
+    assert L.ddsp_mss_scale_supported(512) == 1 and L.ddsp_mss_scale_supported(96) == 0 and L.ddsp_mss_scale_supported(4096) == 0
+    assert L.ddsp_mss_scale_scratch_bytes() > 0
+    assert L.ddsp_mss_scale(None, None, None, None, None, None, 1, 4096, 512, 128, 1.0, 1e-7, None) == -1     # no output word
+    assert L.ddsp_colsum(None, None, None, 8, 0, 0, None) == 0 and L.ddsp_colsum(None, None, None, 8, 4, 0, None) == -1
+    assert L.ddsp_colsum_scratch_bytes(512) > 0 and L.ddsp_colsum_scratch_bytes(0) == 0
+    assert L.ddsp_noise_backward_counter(None, None, 1, 1, 65, 128, 0, None, None) == -1
+    assert L.ddsp_reverb_impulse(None, None, None, None, None, 16, 16, None) == -1
 
 
 def test_module_boundary_matches_reference_contract():
