@@ -3,13 +3,17 @@ and a data-parallel step with ONE flat RCCL all-reduce of the gradients.
 
 * `MSSLoss` restates loss/mss_loss.py:11-68.  The reference builds its spectrograms with
   torchaudio.transforms.Spectrogram (pinned torchaudio==0.8.1, requirements.txt:111), which is not
-  installed here: this is the documented equivalent on torch.stft -- **parity unpinned** (no reference
-  fixture can be produced for it).
+  installed here: this is the documented equivalent on torch.stft semantics -- **parity unpinned** (no reference
+  fixture can be produced for it).  CPU tensors run the torch formulation; on CUDA fp32 tensors every scale is ONE HIP kernel
+  (framing, in-LDS FFTs, loss terms, gradient frames: `_FusedScales`, csrc/ddsp_mss_fft.hip) for the trainer's power-of-two
+  transform sizes, HIP framing around a library rfft + one fused loss pass otherwise.
 * The reference trains on a single GPU (train/train.py:50); the data-parallel step is new design:
   replicas, per-rank batch shard, gradients flattened into one bucket (19.35 MB for the 16 kHz/100/65
   decoder) and averaged with a single all_reduce.  Design estimate, NOT measured (no run on more than one
   physical GPU exists yet; two-process tests on one GPU cover correctness only): on 8 MI355X a ring moves
   2*7/8 of the bucket per GPU over xGMI, which should be latency- rather than bandwidth-bound -- hence one bucket.
+  The alternative ships as well: `OverlappedGradientReducer` (a few buckets whose all-reduces start during the backward).
+* `GraphedTrainStep` (graphed.py) replays the whole step as a hipGraph.
 """
 from __future__ import annotations
 
