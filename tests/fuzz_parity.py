@@ -4,7 +4,7 @@ net, run by tests/test_gpu_fuzz.py with a fixed seed and from the command line f
 random batch / frames / harmonics / hop / sample rate / noise bands, both f0 kinds, power-of-two and odd hops, hops 256 / 512
 (in-LDS FFT noise form, impulse shorter than / equal to / longer than the hop).  Prints one line per case and a summary;
 exit code 1 if any case exceeds the tolerances the tests assert (audio 1e-5, noise 2e-6 of max(1, |y|), phases bit-exact).
-usage: fuzz_parity.py [cases] [seed]"""
+usage: fuzz_parity.py [cases] [seed] [training]   (`training`: the loss-side kernels against fp64 torch instead)"""
 import os
 import sys
 
@@ -130,6 +130,10 @@ def sweep_training_kernels(cases: int, seed: int, verbose: bool = True):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
+    if len(sys.argv) > 3 and sys.argv[3] == "training":
+        bad = sweep_training_kernels(cases, seed, verbose=False)
+        print(f"loss-side kernels (one-kernel spectral scales, framing, column sums): cases {cases}, seed {seed}, failed {bad}")
+        sys.exit(1 if bad else 0)
     bad, worst_osc, worst_noise = sweep(cases, seed)
     print(f"cases {cases}, failed {bad}, worst audio error {worst_osc:.2e}, worst noise error {worst_noise:.2e}")
     sys.exit(1 if bad else 0)
