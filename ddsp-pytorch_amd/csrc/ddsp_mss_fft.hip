@@ -258,11 +258,17 @@ hipError_t launch(const MssParams &p0, hipStream_t s, int *blocks_out)
     constexpr int PTS = N > 1024 ? N : 1024;
     constexpr int SLOTS = PTS / N;
     const size_t lds = sizeof(float2) * (3 * PTS + N) + sizeof(float) * N + sizeof(SlotInfo) * SLOTS;
-    static bool raised = false;     // > 64 KiB of dynamic LDS needs the opt-in (n_fft = 2048: 72 KiB)
-    if (lds > 64 * 1024 && !raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mss_scale_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) {          // n_fft = 2048: 72 KiB of dynamic LDS needs the opt-in, once per device (the kernel also holds a
+                                    // few static words, so the ceiling asked for is what it uses, not the whole 160 KiB)
+        static bool raised[64] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
-        raised = true;
+        if (!raised[dev & 63]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mss_scale_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            raised[dev & 63] = true;
+        }
     }
     MssParams p = p0;
     const long groups = (p.npairs + SLOTS - 1) / SLOTS;
