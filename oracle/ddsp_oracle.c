@@ -192,6 +192,54 @@ int ddsp_oracle_noise(const float *Hm, const float *u, float *y, float *dbg_ir, 
     return 0;
 }
 
+/*
+ * Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; the Random123
+ * library's philox4x32 with its default 10 rounds).  Restated from the paper: multipliers 0xD2511F53 / 0xCD9E8D57,
+ * Weyl key increments 0x9E3779B9 / 0xBB67AE85 applied between rounds.  Pinned by the library's published
+ * known-answer vectors (tests/test_oracle_golden.py::test_philox_known_answers).
+ * This is the generator behind FilteredNoise(rng='device') -- the throughput replacement of the reference's
+ * torch.rand draw (filtered_noise.py:44-48); the reference itself has no counterpart, so the KAT vectors are the pin.
+ */
+void ddsp_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/*
+ * The uniform draw of the in-kernel stream, laid out like torch.rand(B,T,R) (include/ddsp_hip.h, ddsp_noise_forward):
+ * frame f (= b*T + t), sample m: word (m & 3) of Philox(counter = offset + f*ceil(R/4) + (m >> 2), key = seed),
+ * counter and key as 64-bit values split low word first, upper counter words 0; u = (word >> 8) * 2^-24 in [0,1).
+ * The kernels then form x = 2u - 1 exactly as the reference does with its own draw (:45).
+ */
+int ddsp_oracle_philox_uniform(uint64_t seed, uint64_t offset, int64_t frames, int R, float *u)
+{
+    if (frames < 0 || R <= 0) return 1;
+    const int64_t quads = (R + 3) / 4;
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma omp parallel for schedule(static)
+    for (int64_t f = 0; f < frames; ++f)
+        for (int64_t q = 0; q < quads; ++q) {
+            const uint64_t c = offset + (uint64_t)f * (uint64_t)quads + (uint64_t)q;
+            const uint32_t ctr[4] = {(uint32_t)c, (uint32_t)(c >> 32), 0u, 0u};
+            uint32_t w[4];
+            ddsp_oracle_philox4x32_10(ctr, key, w);
+            for (int e = 0; e < 4 && 4 * q + e < R; ++e) u[f * R + 4 * q + e] = (float)(w[e] >> 8) * (1.0f / 16777216.0f);
+        }
+    return 0;
+}
+
 int ddsp_oracle_threads(void)
 {
 #ifdef _OPENMP

@@ -39,6 +39,11 @@ def lib():
         _lib.ddsp_oracle_noise.restype = ctypes.c_int
         _lib.ddsp_oracle_noise.argtypes = [_fp] * 4 + [ctypes.c_int] * 4
         _lib.ddsp_oracle_threads.restype = ctypes.c_int
+        _u32p = ctypes.POINTER(ctypes.c_uint32)
+        _lib.ddsp_oracle_philox4x32_10.restype = None
+        _lib.ddsp_oracle_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
+        _lib.ddsp_oracle_philox_uniform.restype = ctypes.c_int
+        _lib.ddsp_oracle_philox_uniform.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int, _fp]
     return _lib
 
 
@@ -84,10 +89,32 @@ def osc_frames(f0, c, sample_rate: int):
     return w, amp
 
 
-def noise_forward(Hm, uniform, hop: int, debug: bool = False):
-    """FilteredNoise.forward with the torch.rand draw `uniform` [B,T,hop] injected. -> y [B,T*hop]."""
-    Hm, uniform = _f32(Hm), _f32(uniform)
+def philox4x32_10(counter, key):
+    """One Philox4x32-10 block: counter (4 x u32), key (2 x u32) -> 4 x u32 (Random123 word order)."""
+    c = (ctypes.c_uint32 * 4)(*[int(v) & 0xFFFFFFFF for v in counter])
+    k = (ctypes.c_uint32 * 2)(*[int(v) & 0xFFFFFFFF for v in key])
+    out = (ctypes.c_uint32 * 4)()
+    lib().ddsp_oracle_philox4x32_10(c, k, out)
+    return [int(v) for v in out]
+
+
+def philox_uniform(seed: int, offset: int, batch: int, frames: int, hop: int):
+    """The in-kernel draw of FilteredNoise(rng='device') as the [B,T,hop] uniform tensor torch.rand would have been."""
+    u = np.empty((batch, frames, hop), np.float32)
+    rc = lib().ddsp_oracle_philox_uniform(int(seed) & (2**64 - 1), int(offset) & (2**64 - 1), batch * frames, hop, _p(u))
+    assert rc == 0
+    return u
+
+
+def noise_forward(Hm, uniform, hop: int, debug: bool = False, seed=None, offset: int = 0):
+    """FilteredNoise.forward with the torch.rand draw `uniform` [B,T,hop] injected. -> y [B,T*hop].
+    `uniform=None` with `seed` (and `offset`): the draw of the in-kernel Philox stream is regenerated here."""
+    Hm = _f32(Hm)
     B, T, F = Hm.shape
+    if uniform is None:
+        assert seed is not None, "either an injected draw or the seed of the in-kernel stream"
+        uniform = philox_uniform(seed, offset, B, T, hop)
+    uniform = _f32(uniform)
     assert uniform.shape == (B, T, hop)
     y = np.empty((B, T * hop), np.float32)
     ir = np.empty((B, T, hop), np.float32) if debug else None

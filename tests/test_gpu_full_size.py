@@ -73,6 +73,12 @@ def test_noise_full_size_properties():
     assert torch.equal(yb, ya[idx])
     ref = oracle.noise_forward(ctl["H"][:2], u[:2].cpu().numpy(), shape.hop)
     assert np.max(np.abs(ya[:2].cpu().numpy() - ref)) <= 2e-6
+    # the configuration bench.py times -- the in-kernel Philox draw -- three whole rows against the oracle, which regenerates
+    # the stream: row b starts at counter b * T * hop/4
+    quads = shape.hop // 4
+    for b in (0, shape.batch // 2, shape.batch - 1):
+        ref = oracle.noise_forward(ctl["H"][b:b + 1], None, shape.hop, seed=5, offset=b * shape.frames * quads)
+        assert np.max(np.abs(y[b:b + 1].cpu().numpy() - ref)) <= 2e-6, b
 
 
 def test_cfg3_shape_slice_against_oracle():
@@ -169,6 +175,10 @@ def test_cfg3_whole_workload():
     n2 = ddsp.noise_forward(2.0 * x["H"], shape.hop, seed=9)
     assert torch.equal(n2, 2.0 * n1)
     del n2
+    # ... and three whole rows of that in-kernel draw against the oracle regenerating the Philox stream (what bench.py's cfg3 line times)
+    for b in rows:
+        dref = oracle.noise_forward(ctl["H"][b:b + 1], None, shape.hop, seed=9, offset=b * shape.frames * (shape.hop // 4))
+        assert np.max(np.abs(n1[b:b + 1].cpu().numpy() - dref)) <= 2e-6 * max(1.0, float(np.max(np.abs(dref)))), b
     u = np.random.default_rng(33).random((3, shape.frames, shape.hop), dtype=np.float32)
     hrows = x["H"][rows].contiguous()
     got = ddsp.noise_forward(hrows, shape.hop, uniform=torch.from_numpy(u).cuda())

@@ -172,6 +172,66 @@ def test_noise_device_rng_statistics_and_accumulate():
     assert torch.allclose(out, base + y1, atol=1e-6)
 
 
+# ---- the in-kernel draw (rng='device', what bench.py times) against the oracle's Philox4x32-10 restatement -------------
+# (the oracle's generator is pinned by the Random123 known-answer vectors: tests/test_oracle_golden.py)
+FORMS = {"batched": (0, 128), "generic": (1, 128), "generic_ragged_hop": (1, 6), "batched_hop512": (2, 512), "fft": (0, 512), "fft_hop256": (4, 256)}
+
+
+@pytest.mark.parametrize("form", sorted(FORMS))
+@pytest.mark.parametrize("seed,offset", [(0, 0), (0x9E3779B97F4A7C15, (1 << 40) + 12345), (7, (1 << 32) - 5)])
+def test_noise_device_draw_is_the_oracles_philox_stream(form, seed, offset):
+    """F = 2, H = 1: z = irfft([1, 1]) = [1, 0] exactly, so the impulse response is a unit tap and y must BE the draw,
+    x = 2u - 1 with u = (word >> 8) * 2^-24 -- sample for sample (bit-exact in the time-domain kernels, to FFT rounding in the
+    FFT form).  seed 0 / offset 0 starts at the Random123 known-answer block; the large offsets carry into the counter's high word."""
+    mode, hop = FORMS[form]
+    B, T = 3, 7                                    # 21 frames: a ragged last tile / a half-empty last frame pair
+    H = torch.ones(B, T, 2, device="cuda")
+    L = ddsp._lib.lib()
+    L.ddsp_noise_set_generic(mode)
+    try:
+        y = ddsp.noise_forward(H, hop, seed=seed, offset=offset).cpu().numpy()
+    finally:
+        L.ddsp_noise_set_generic(0)
+    x = oracle.philox_uniform(seed, offset, B, T, hop).reshape(B, T * hop) * 2.0 - 1.0
+    if form.startswith("fft"):
+        assert np.max(np.abs(y - x)) <= 2e-6
+    else:
+        assert np.array_equal(y, x)
+    if seed == 0 and offset == 0:                  # the first block is the published vector 6627e8d5 e169c58d bc57ac4c 9b00dbd8
+        want = np.array([0x6627e8d5 >> 8, 0xe169c58d >> 8, 0xbc57ac4c >> 8, 0x9b00dbd8 >> 8], np.float64) / 2.0 ** 24 * 2.0 - 1.0
+        assert np.max(np.abs(y[0, :4] - want)) <= (2e-6 if form.startswith("fft") else 0.0)
+
+
+@pytest.mark.parametrize("hop,nf,mode", [(128, 65, 0), (128, 65, 1), (64, 65, 0), (512, 257, 0), (512, 257, 2), (512, 195, 0), (256, 129, 0), (256, 129, 4), (24, 7, 0)])
+def test_noise_device_rng_vs_oracle(hop, nf, mode):
+    """Real filters with the in-kernel draw, every kernel form: the oracle regenerates the same Philox stream (seed, offset)."""
+    rng = np.random.default_rng(hop * 3 + nf)
+    B, T = 2, 13
+    Hn = syn.controller_range(rng.standard_normal((B, T, nf), dtype=np.float32))
+    seed, offset = 1234, (5 << 32) + 77
+    L = ddsp._lib.lib()
+    L.ddsp_noise_set_generic(mode)
+    try:
+        y = ddsp.noise_forward(dev(Hn), hop, seed=seed, offset=offset).cpu().numpy()
+    finally:
+        L.ddsp_noise_set_generic(0)
+    ref = oracle.noise_forward(Hn, None, hop, seed=seed, offset=offset)
+    assert np.max(np.abs(y - ref)) <= 2e-6 * max(1.0, float(np.max(np.abs(ref))))
+
+
+def test_filtered_noise_module_device_stream_advances_like_the_oracle():
+    """FilteredNoise(rng='device'): call k draws from offset = sum of the earlier calls' counters (B*T*ceil(hop/4))."""
+    fn = ddsp.FilteredNoise(Conf(1, 16000, 128), rng="device", seed=99)
+    rng = np.random.default_rng(12)
+    off = 0
+    for B, T in ((2, 5), (1, 3), (3, 4)):
+        Hn = syn.controller_range(rng.standard_normal((B, T, 65), dtype=np.float32))
+        y = fn({"H": dev(Hn)}).cpu().numpy()
+        ref = oracle.noise_forward(Hn, None, 128, seed=99, offset=off)
+        assert np.max(np.abs(y - ref)) <= 2e-6
+        off += B * T * 32
+
+
 def test_decoder_wiring_g11():
     # decoder.py:129-133: harmonics + noise (reverb is a "next" row, applied here by the fixture's own impulse)
     g = load_golden("g11_decoder_wiring")

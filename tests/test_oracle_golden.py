@@ -146,3 +146,41 @@ def test_c_noise_oracle_equals_torch_restatement_random(seed):
     y = oracle.noise_forward(Hm, u, hop)
     yt = tr.filtered_noise(torch.from_numpy(Hm), hop, uniform=torch.from_numpy(u)).numpy()
     assert np.max(np.abs(y - yt)) <= 3e-6 * max(1.0, float(np.max(np.abs(yt))))
+
+
+# ---- the in-kernel noise stream (FilteredNoise(rng='device')): Philox4x32-10 ---------------------------------------
+# Known-answer vectors published with the Random123 library (kat_vectors, "philox4x32 10" lines): counter, key -> output.
+PHILOX_KAT = [
+    ([0x00000000] * 4, [0x00000000] * 2, [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0], [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+]
+
+
+@pytest.mark.parametrize("ctr,key,want", PHILOX_KAT)
+def test_philox_known_answers(ctr, key, want):
+    assert oracle.philox4x32_10(ctr, key) == want
+
+
+def test_philox_uniform_layout():
+    """counter = offset + frame * ceil(hop/4) + quad, key = seed (64-bit, low word first), u = (word >> 8) * 2^-24."""
+    # seed 0 / offset 0: the first four samples are the first KAT vector's words
+    u = oracle.philox_uniform(0, 0, 1, 2, 8)
+    want = np.array([w >> 8 for w in PHILOX_KAT[0][2]], np.float64) / 2.0 ** 24
+    assert np.array_equal(u[0, 0, :4].astype(np.float64), want)
+    # a ragged hop (6 -> two counters per frame, the second half used), a 64-bit offset that carries into the high word
+    seed, off, hop = 0x0123456789ABCDEF, (1 << 32) - 3, 6
+    u = oracle.philox_uniform(seed, off, 2, 3, hop)
+    for f in range(6):
+        for m in range(hop):
+            c = off + f * 2 + (m >> 2)
+            w = oracle.philox4x32_10([c & 0xFFFFFFFF, c >> 32, 0, 0], [seed & 0xFFFFFFFF, seed >> 32])[m & 3]
+            assert float(u.reshape(6, hop)[f, m]) == (w >> 8) / 2.0 ** 24
+    assert u.min() >= 0.0 and u.max() < 1.0
+
+
+def test_noise_oracle_regenerates_the_device_draw():
+    rng = np.random.default_rng(4)
+    H = rng.uniform(0.0, 2.0, (2, 3, 9)).astype(np.float32)
+    u = oracle.philox_uniform(11, 5, 2, 3, 16)
+    assert np.array_equal(oracle.noise_forward(H, None, 16, seed=11, offset=5), oracle.noise_forward(H, u, 16))
