@@ -60,6 +60,54 @@ from ddsp_pytorch_amd import synthetic as syn  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TLANEOPS = 78.6      # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (= 157.3 TFLOP/s fp32 vector / 2)
 SYNTH_OPS = 11                 # VALU instructions of the synth kernel per harmonic-sample (12 and 10 on alternate samples)
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # fp32 vector peak (FMA = 2 flop)
+SURVEY_FLOPS_PER_HS = 27       # algorithmic flops per harmonic-sample of the whole oscillator path
+KERNELS = ("osc_frame_totals", "osc_scan", "osc_frame_synth", "noise_frame")
+
+
+def gather_rows(dist, row, world, rank):
+    """Every rank's `row` (a list of floats) on every rank, as a [world, len(row)] array: an all-reduce(SUM) of a matrix in
+    which each rank filled its own line -- works on every backend (RCCL and the gloo rehearsal) without object pickling."""
+    m = torch.zeros(world, len(row), device="cuda", dtype=torch.float64)
+    m[rank] = torch.tensor(row, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(m, op=dist.ReduceOp.SUM)
+    return m.cpu().numpy()
+
+
+def time_config(shape, seed, steps, warmup, f0_kind="all_live", noise_seed=7):
+    """One BASELINE.json configuration on this GPU: `steps` passes of OscillatorBank.forward + FilteredNoise accumulated
+    (in-kernel draw), inputs resident.  -> dict (ms_per_step by the host clock around a synchronised region, per-kernel
+    averages from HIP events on the launch stream)."""
+    ctl = syn.make_controls(shape, seed, f0_kind)
+    x = {k: torch.from_numpy(v).cuda() for k, v in ctl.items()}
+    osc = ddsp.OscillatorBank(Conf(shape)).cuda()
+
+    def step(i):
+        y = osc(x)
+        ddsp.noise_forward(x["H"], shape.hop, seed=noise_seed, offset=i << 32, out=y, accumulate=True)
+        return y
+
+    for i in range(warmup):
+        y = step(i)
+    ddsp._lib.profile_enable(8 * steps + 16)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        y = step(warmup + i)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    rec = {}
+    for name, ms in ddsp._lib.profile_read():
+        rec.setdefault(name, []).append(ms)
+    ddsp._lib.profile_enable(0)
+    assert bool(torch.isfinite(y).all()), "non-finite audio"
+    del y, x, osc
+    torch.cuda.empty_cache()
+    return {"workload": f"batch {shape.batch}, {shape.sample_rate} Hz, {shape.n_harmonics} harmonics, hop {shape.hop}, "
+                        f"{shape.frames} frames (4 s), {shape.n_noise_filters} noise bands, {f0_kind} f0, in-kernel noise draw",
+            "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * el, "samples_per_s": shape.batch * shape.samples / el,
+            "kernel_ms": {k: float(np.mean(v)) for k, v in rec.items()}}
 
 
 class Conf:
@@ -165,10 +213,27 @@ def train_mode(args, rank, world, dist):
     submitted = time.perf_counter() - t0                     # host time to ISSUE the steps (nothing in a step synchronises)
     fence()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
     if dist is not None:
         tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    # the gradient all-reduce on its own (after the timed region): the flat fp32 bucket of this model, 10 rounds between events --
+    # what one step pays when nothing overlaps it; decides "one flat bucket" against --overlap-allreduce on the first real run
+    allreduce_ms = None
+    if dist is not None:
+        flat = torch.zeros(max(1, nbytes // 4), device="cuda", dtype=torch.float32)
+        for _ in range(2):
+            dist.all_reduce(flat)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fence()
+        e0.record()
+        for _ in range(10):
+            dist.all_reduce(flat)
+        e1.record()
+        torch.cuda.synchronize()
+        allreduce_ms = e0.elapsed_time(e1) / 10.0
+    per_rank = gather_rows(dist, [1e3 * own_elapsed / args.steps, allreduce_ms or 0.0], world, rank)
     if rank == 0:
         print(json.dumps({
             "metric": "train-step audio samples/sec (BASELINE.json configs[4]; secondary figure)",
@@ -181,6 +246,11 @@ def train_mode(args, rank, world, dist):
                                    f"16 kHz, 100 harmonics, 65 noise bands, 4 s", "parallelism": f"dp{world}, " + ("bucketed all-reduces overlapping the backward" if (args.overlap_allreduce and world > 1 and not args.graph)
                                                           else "one flat all-reduce") + (", step captured as a hipGraph" if args.graph else ""),
                        "allreduce_bytes": nbytes},
+            "allreduce_ms": allreduce_ms, "allreduce_GBps_per_rank": (nbytes / (allreduce_ms * 1e-3) / 1e9) if allreduce_ms else None,
+            "per_rank_ms": [float(v) for v in per_rank[:, 0]], "per_rank_allreduce_ms": [float(v) for v in per_rank[:, 1]],
+            "slowest_rank": int(np.argmax(per_rank[:, 0])),
+            "collective_backend": dist.get_backend() if dist is not None else None,
+            "rccl_ranks": dist.get_world_size() if dist is not None else 1,
             "final_loss": float(loss)}), flush=True)
     if dist is not None:
         dist.barrier()
@@ -197,6 +267,8 @@ def main():
     ap.add_argument("--tiling", type=int, default=0, help="force harmonics per lane (tuning)")
     ap.add_argument("--harmonics", type=int, default=0, help="override the number of harmonics (tuning experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary BASELINE.json configurations (cfg2, cfg3) timed after the headline at N = 1")
     ap.add_argument("--mode", default="synth", choices=["synth", "train"],
                     help="synth: the headline hot path; train: BASELINE.json configs[4] (decoder + MSS loss + Adam, "
                          "batch 32/GPU, flat RCCL gradient all-reduce) -- a secondary figure, not the metric")
@@ -246,6 +318,7 @@ def main():
     osc = ddsp.OscillatorBank(conf).cuda()
     uniform = torch.rand(shape.batch, shape.frames, shape.hop, device="cuda") if args.noise == "resident" else None
     if args.tiling:
+        assert ddsp._lib.lib().ddsp_test_hooks_enabled(), "--tiling is a tuning hook: run with DDSP_TEST_HOOKS=1"
         ddsp._lib.check(ddsp._lib.lib().ddsp_osc_set_tiling(args.tiling), "ddsp_osc_set_tiling")
 
     def step(i):
@@ -271,17 +344,22 @@ def main():
     records = ddsp._lib.profile_read()
     ddsp._lib.profile_enable(0)
     assert bool(torch.isfinite(y).all()), "non-finite audio"
+    own_elapsed = elapsed
     if dist is not None:
         tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    per_kernel = {}
+    for name, ms in records:
+        per_kernel.setdefault(name, []).append(ms)
+    kern_ms = {k: float(np.mean(v)) for k, v in per_kernel.items()}
+    # every rank's own clock and per-kernel averages, gathered so that the first multi-GPU run diagnoses itself: a slow rank
+    # (clock, thermal, a noisy neighbour on its XCDs) shows up by index instead of hiding inside the MAX
+    diag = gather_rows(dist, [1e3 * own_elapsed / args.steps] + [kern_ms.get(k, float("nan")) for k in KERNELS], world, rank)
+    del y
 
     if rank == 0:
         samples_per_step = world * shape.batch * shape.samples
-        per_kernel = {}
-        for name, ms in records:
-            per_kernel.setdefault(name, []).append(ms)
-        kern_ms = {k: float(np.mean(v)) for k, v in per_kernel.items()}
         synth_ms = kern_ms.get("osc_frame_synth", float("nan"))
         # algorithmic bytes of the oscillator per output sample = 4 (y) + 4*(H+2)/hop (c, f0, a)
         bytes_per_sample = 4.0 + 4.0 * (shape.n_harmonics + 2) / shape.hop
@@ -329,7 +407,14 @@ def main():
                          "note": "kernel is VALU-bound (SURVEY §8d): see valu",
                          "valu": {"harmonic_samples_per_s": hs_per_s, "lane_ops_per_harmonic_sample": SYNTH_OPS,
                                   "achieved_Tlaneops": hs_per_s * SYNTH_OPS / 1e12, "peak_Tlaneops": VALU_PEAK_TLANEOPS,
-                                  "frac": hs_per_s * SYNTH_OPS / 1e12 / VALU_PEAK_TLANEOPS},
+                                  "frac": hs_per_s * SYNTH_OPS / 1e12 / VALU_PEAK_TLANEOPS,
+                                  # SURVEY §8(d)'s own accounting: 27 algorithmic flops per harmonic-sample of the whole path
+                                  # against the 157.3 TFLOP/s fp32 vector peak, (a) for this kernel's launch, (b) for the whole step
+                                  "survey_flops_per_harmonic_sample": SURVEY_FLOPS_PER_HS, "survey_peak_TFLOPs": FP32_VECTOR_PEAK_TFLOPS,
+                                  "survey_achieved_TFLOPs": hs_per_s * SURVEY_FLOPS_PER_HS / 1e12,
+                                  "survey_frac": hs_per_s * SURVEY_FLOPS_PER_HS / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                                  "survey_frac_whole_step": (launch_samples * shape.n_harmonics / (elapsed / args.steps))
+                                                            * SURVEY_FLOPS_PER_HS / 1e12 / FP32_VECTOR_PEAK_TFLOPS},
                          "noise_frame": {"bound": "hbm", "kernel": "noise_frame", "achieved": noise_achieved, "peak": HBM_PEAK_GBS,
                                          "unit": "GB/s", "frac": noise_achieved / HBM_PEAK_GBS, "traffic": traffic_of("noise_batched_kernel"),
                                          "algorithmic_bytes_per_launch": launch_samples * noise_bps,
@@ -340,7 +425,19 @@ def main():
                                                   "peak_Tlaneops": VALU_PEAK_TLANEOPS,
                                                   "frac": launch_samples * noise_macs / (noise_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS}}},
             "kernel_ms": kern_ms,
+            "per_rank_ms": [float(v) for v in diag[:, 0]],
+            "per_rank_kernel_ms": {k: [float(v) for v in diag[:, 1 + j]] for j, k in enumerate(KERNELS)},
+            "slowest_rank": int(np.argmax(diag[:, 0])),
+            "collective_backend": dist.get_backend() if dist is not None else None,
+            "rccl_ranks": dist.get_world_size() if dist is not None else 1,
         }
+        if world == 1 and not args.no_secondary and not (args.batch or args.harmonics or args.tiling):
+            # SECONDARY figures, timed AFTER (outside) the headline's timed region: BASELINE.json configs[1] and configs[2] on this GPU,
+            # 10 steps each.  `value` above is the metric's configuration only.
+            del x, osc
+            torch.cuda.empty_cache()
+            line["configs"] = {"note": "secondary: timed after the headline region, 10 steps each, not part of `value`",
+                               "cfg2": time_config(syn.CFG2, 1002, 10, 2), "cfg3": time_config(syn.CFG3, 1003, 10, 2)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(shape)
         print(json.dumps(line), flush=True)

@@ -11,7 +11,7 @@ import subprocess
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("DDSP_HIP_LIB", os.path.join(_DIR, "libddsp_hip.so"))  # override: A/B builds (tools/ab_bench.sh)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -43,6 +43,12 @@ def lib():
     vp, i32, u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64
     L.ddsp_hip_abi_version.restype = i32
     L.ddsp_hip_abi_version.argtypes = []
+    # first of all: a stale library (it is git-ignored and not rebuilt on import) must say "rebuild", not fail on a missing symbol
+    if L.ddsp_hip_abi_version() != ABI_VERSION:
+        raise DdspHipError(f"{SO_PATH} has ABI {L.ddsp_hip_abi_version()}, expected {ABI_VERSION}: rebuild "
+                           "(`make -C ddsp-pytorch_amd/csrc` or __graft_entry__.build())")
+    L.ddsp_test_hooks_enabled.restype = i32
+    L.ddsp_test_hooks_enabled.argtypes = []
     L.ddsp_osc_scratch_bytes.restype = ctypes.c_size_t
     L.ddsp_osc_scratch_bytes.argtypes = [i32, i32, i32]
     L.ddsp_osc_forward.restype = i32
@@ -129,13 +135,11 @@ def lib():
     L.ddsp_reverb_live_scratch_bytes.argtypes = [i32, i32]
     L.ddsp_reverb_live.restype = i32
     L.ddsp_reverb_live.argtypes = [vp] * 9 + [i32, i32, vp]
-    if L.ddsp_hip_abi_version() != ABI_VERSION:
-        raise DdspHipError(f"libddsp_hip.so has ABI {L.ddsp_hip_abi_version()}, expected {ABI_VERSION}: rebuild")
     _lib = L
     return L
 
 
-EXPORTS = ("ddsp_hip_abi_version", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_noise_forward", "ddsp_noise_forward_counter",
+EXPORTS = ("ddsp_hip_abi_version", "ddsp_test_hooks_enabled", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_noise_forward", "ddsp_noise_forward_counter",
            "ddsp_osc_backward_scratch_bytes", "ddsp_osc_backward", "ddsp_noise_backward", "ddsp_noise_backward_counter",
            "ddsp_osc_set_tiling", "ddsp_noise_set_generic", "ddsp_profile_enable", "ddsp_profile_read",
            "ddsp_gru_scratch_bytes", "ddsp_gru_max_batch", "ddsp_gru_forward", "ddsp_gru_backward", "ddsp_gru_forward_bf16", "ddsp_gru_backward_bf16", "ddsp_gru_status", "ddsp_gru_set_mode", "ddsp_gru_set_fault_step",
@@ -166,4 +170,6 @@ def check(rc: int, what: str) -> None:
         raise DdspHipError(f"{what}: invalid argument (DDSP_EINVAL)")
     if rc == -2:
         raise DdspHipError(f"{what}: shape outside the supported range (DDSP_ERANGE)")
+    if rc == -3:
+        raise DdspHipError(f"{what}: test / tuning hook refused (DDSP_EPERM): set DDSP_TEST_HOOKS=1 before the library is loaded")
     raise DdspHipError(f"{what}: HIP error {rc}")

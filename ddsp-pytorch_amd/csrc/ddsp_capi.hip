@@ -7,7 +7,16 @@
 #include "ddsp_hip.h"
 #include "ddsp_internal.h"
 
+#include <stdlib.h>
+
 extern "C" int ddsp_hip_abi_version(void) { return DDSP_HIP_ABI_VERSION; }
+
+namespace {
+// read ONCE, when the shared object is loaded: a later setenv cannot arm the hooks of a running process
+const bool g_hooks_on = [] { const char *e = getenv("DDSP_TEST_HOOKS"); return e && e[0] == '1' && e[1] == 0; }();
+}  // namespace
+bool ddsp_hooks_on() { return g_hooks_on; }
+extern "C" int ddsp_test_hooks_enabled(void) { return g_hooks_on ? 1 : 0; }
 
 namespace {
 struct Record { hipEvent_t t0, t1; int kernel_id; };

@@ -1170,6 +1170,7 @@ extern "C" int ddsp_gru_backward_bf16(const float *dy, const float *dhT, const f
 extern "C" int ddsp_gru_set_mode(int mode)
 {
     if (mode < 0 || mode > 3) return DDSP_ERANGE;
+    if (mode != 0 && !ddsp_hooks_on()) return DDSP_EPERM;
     g_gru_mode.store(mode, std::memory_order_relaxed);
     return 0;
 }
@@ -1177,6 +1178,7 @@ extern "C" int ddsp_gru_set_mode(int mode)
 extern "C" int ddsp_gru_set_fault_step(int step)
 {
     if (step < 0) return DDSP_ERANGE;
+    if (!ddsp_hooks_on()) return DDSP_EPERM;
     g_gru_fault_step.store(step, std::memory_order_relaxed);
     return 0;
 }

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// DDSP_TEST_HOOKS=1 at load time (ddsp_capi.hip): the process-global *_set_* hooks are live; otherwise they refuse.
+bool ddsp_hooks_on();
+
 namespace ddsp_prof {
 enum KernelId { PREP = 0, TOTALS = 1, SCAN = 2, SYNTH = 3, NOISE = 4 };
 // Record an event pair around one launch on `s` when profiling is enabled (no-ops otherwise).

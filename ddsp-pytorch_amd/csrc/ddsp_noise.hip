@@ -634,6 +634,7 @@ int noise_forward_impl(const float *Hmag, const float *uniform, float *y, int B,
 
 extern "C" int ddsp_noise_set_generic(int on)
 {
+    if (on != 0 && !ddsp_hooks_on()) return DDSP_EPERM;
     g_force_generic.store(on, std::memory_order_relaxed);
     return 0;
 }

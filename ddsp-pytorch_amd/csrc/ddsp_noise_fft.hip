@@ -508,7 +508,9 @@ hipError_t launch(const NoiseParams &p, hipStream_t s)
     const long by_regs = R1 == 16 ? 12 : 20, by_lds = (160 * 1024) / (long)lds;
     long per_cu = by_lds < by_regs ? by_lds : by_regs;
     if (per_cu > 4) per_cu -= per_cu % 4;    // the same number of wavefronts on each of the CU's four SIMDs (measured: 9 per CU is slower than 8)
-    if (const char *ev = getenv("DDSP_NOISE_FFT_WAVES")) { const long v = atol(ev); if (v > 0 && v < per_cu) per_cu = v; }   // tuning experiments
+    // tuning experiments (DDSP_TEST_HOOKS=1 processes only; read once)
+    static const long env_waves = [] { const char *ev = getenv("DDSP_NOISE_FFT_WAVES"); return (ev && ddsp_hooks_on()) ? atol(ev) : 0L; }();
+    if (env_waves > 0 && env_waves < per_cu) per_cu = env_waves;
     const long resident = (long)cus * per_cu;
     const long grid = npairs < resident ? npairs : resident;
     const int slot = ddsp_prof::begin(ddsp_prof::NOISE, s);

@@ -609,6 +609,7 @@ bool setup_params(OscParams &p, void *scratch, int B, int T, int H, int hop, int
 extern "C" int ddsp_osc_set_tiling(int harmonics_per_lane)
 {
     if (harmonics_per_lane != 0) {
+        if (!ddsp_hooks_on()) return DDSP_EPERM;
         bool known = false;
         for (int K : kKs) known = known || (K == harmonics_per_lane);
         if (!known) return DDSP_ERANGE;

@@ -52,11 +52,15 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
 class LowpWeights:
     """Low-precision copies of the dense layers' parameters for torch.autocast steps, refreshed by ONE multi-tensor copy per
     step instead of a cast launch per parameter and layer (31 launches at the training shape).  `refresh(dtype)` is called once
-    before the forward (train_step does) and renews the copies of every parameter `_Linear` has asked for so far; `_Linear` takes
-    a copy only while the parameter has not been written since (`_version` unchanged), so a stale copy can never be used."""
+    before the forward (train_step and GraphedTrainStep do) and renews -- unconditionally: it is one `_foreach_copy_` -- the
+    copies of every parameter `_Linear` has asked for so far, then `release()` is called after the forward.  `_Linear` takes
+    a copy only inside that refresh..release window AND while the parameter's `_version` and storage address are what they
+    were at the refresh.  (`_version` alone is not enough: writes through `p.data` and the optimiser update inside a hipGraph
+    replay do not bump it -- which is why the window exists: outside a step every autocast forward casts afresh.)"""
 
     def __init__(self):
-        self._copies = {}      # id(param) -> [weakref(param), copy or None, version at refresh]
+        self._copies = {}      # id(param) -> [weakref(param), copy or None, version at refresh, data_ptr at refresh]
+        self._live = None      # the dtype of the open refresh..release window
 
     def refresh(self, dtype):
         src, dst = [], []
@@ -66,21 +70,25 @@ class LowpWeights:
                 del self._copies[key]
                 continue
             if e[1] is None or e[1].dtype != dtype or e[1].shape != p.shape or e[1].device != p.device:
-                e[1], e[2] = torch.empty_like(p, dtype=dtype), -1
-            if e[2] != p._version:
-                src.append(p.detach())
-                dst.append(e[1])
-                e[2] = p._version
+                e[1] = torch.empty_like(p, dtype=dtype)
+            src.append(p.detach())
+            dst.append(e[1])
+            e[2], e[3] = p._version, p.data_ptr()
         if src:
             torch._foreach_copy_(dst, src)
+        self._live = dtype
+
+    def release(self):
+        """Close the window: until the next refresh() every request is answered with None (the caller casts afresh)."""
+        self._live = None
 
     def get(self, p, dtype):
         e = self._copies.get(id(p))
         if e is None or e[0]() is not p:
             if p.is_cuda and p.dtype == torch.float32 and isinstance(p, torch.nn.Parameter):
-                self._copies[id(p)] = [weakref.ref(p), None, -1]       # wanted: part of the next refresh
+                self._copies[id(p)] = [weakref.ref(p), None, -1, 0]    # wanted: part of the next refresh
             return None
-        if e[1] is not None and e[2] == p._version and e[1].dtype == dtype:
+        if self._live == dtype and e[1] is not None and e[1].dtype == dtype and e[2] == p._version and e[3] == p.data_ptr():
             return e[1]
         return None
 

@@ -163,7 +163,8 @@ class GraphedTrainStep:
       optimiser did not have yet is zeroed, which is what Adam-style optimisers start from.
     * A `FilteredNoise(rng='device')` inside the model draws from a device-resident Philox counter from here on (read by the
       forward and the backward kernel, advanced by a node of the graph): every replay gets fresh noise, the same sequence as
-      the eager steps.
+      the eager steps; `step()` also advances the modules' host-side offsets by the same amount, so eager calls of the model
+      between graphed steps continue the stream.
     * fp32 or `amp_dtype=torch.bfloat16` (no GradScaler: fp16 needs its host-side decisions); every rank must hold rows.
     * The persistent GRU launches inside a graph are ordered by the graph only: do not run another recurrence on a second
       stream of the same device while a replay is in flight (DESIGN.md par. 9a).
@@ -198,12 +199,15 @@ class GraphedTrainStep:
                 dense.lowp_weights.refresh(self.amp_dtype)
             with torch.autocast("cuda", dtype=self.amp_dtype or torch.bfloat16, enabled=self.amp_dtype is not None):
                 audio = self.model(self.batch)
+            dense.lowp_weights.release()               # (the copies the captured forward uses are refreshed by the graph itself)
             loss = self.loss_fn(audio.float(), self.batch)
             loss.backward()
+            self._draws = [m._last_draws for m in self.noises]     # host constants of the captured shape
             for m, c in zip(self.noises, self.counters):
                 if m._last_draws:                      # (0: the caller injected its own draw, the counter was not read)
                     c.add_(m._last_draws)
         finally:
+            dense.lowp_weights.release()
             for m in self.noises:
                 m.counter = None
         return loss.detach()
@@ -271,6 +275,10 @@ class GraphedTrainStep:
         if self.world > 1:
             self._reduce()
             self._graph_update.replay()
+        # keep the modules' host-side offsets in step with the device counters: an eager call of the same model between or
+        # after graphed steps (validation, an eager train_step) continues the stream instead of replaying its start
+        for m, d in zip(self.noises, self._draws):
+            m._offset += d
         return self.loss, self.nbytes
 
     __call__ = step

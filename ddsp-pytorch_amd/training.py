@@ -330,11 +330,16 @@ def train_step(model: nn.Module, loss_fn: nn.Module, optimizer: torch.optim.Opti
         for p in params:
             p.grad = torch.zeros_like(p)
         loss = torch.zeros((), device=params[0].device if params else "cpu")
+        if scaler is not None:
+            scaler.scale(loss)       # initialises the scaler's state exactly as on the ranks that hold rows (its step() needs it)
     else:
         if amp_dtype is not None:
             dense.lowp_weights.refresh(amp_dtype)       # one multi-tensor cast of the dense layers' parameters per step
-        with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
-            audio = model(batch)
+        try:
+            with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
+                audio = model(batch)
+        finally:
+            dense.lowp_weights.release()                # copies are only valid inside this step's forward
         loss = loss_fn(audio.float(), batch)
         (scaler.scale(loss) if scaler is not None else loss).backward()
     if reducer is not None:

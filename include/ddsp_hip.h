@@ -29,13 +29,23 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_ABI_VERSION 1
+#define DDSP_HIP_ABI_VERSION 2
 
 #define DDSP_EINVAL (-1)   /* null pointer / non-positive size */
 #define DDSP_ERANGE (-2)   /* shape outside what the kernels are built for */
+#define DDSP_EPERM  (-3)   /* a test / tuning hook called in a process that did not opt in (see ddsp_test_hooks_enabled) */
 
 /* ABI version of the loaded library (== DDSP_HIP_ABI_VERSION it was built with). */
 int ddsp_hip_abi_version(void);
+
+/*
+ * The process-global test / tuning hooks below (ddsp_osc_set_tiling, ddsp_noise_set_generic, ddsp_gru_set_mode,
+ * ddsp_gru_set_fault_step) change every later launch of the process.  They only work when the environment variable
+ * DDSP_TEST_HOOKS=1 was set at the moment the library was loaded (tests/conftest.py and the tools/ scripts do that);
+ * in any other process they return DDSP_EPERM for a non-default value and change nothing, so a production process cannot
+ * flip them by accident.  Returns 1 when the hooks are enabled.
+ */
+int ddsp_test_hooks_enabled(void);
 
 /*
  * Bytes of device scratch ddsp_osc_forward needs for a [B,T,H] problem:

@@ -4,6 +4,10 @@ import sys
 import numpy as np
 import pytest
 
+# the process-global *_set_* hooks of libddsp_hip.so (kernel-form selection, fault injection) only work in processes that
+# opted in BEFORE the library was loaded (include/ddsp_hip.h: ddsp_test_hooks_enabled)
+os.environ.setdefault("DDSP_TEST_HOOKS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

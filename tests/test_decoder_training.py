@@ -161,6 +161,10 @@ def test_train_step_with_an_empty_shard():
     loss, nbytes = ddsp.train_step(model, ddsp.MSSLoss((128, 64)), opt, {k: v[lo:hi] for k, v in full.items()})
     assert float(loss) == 0.0 and nbytes == 4 * sum(p.numel() for p in model.parameters())
     assert all(torch.equal(before[k], v) for k, v in model.state_dict().items())
+    # with a GradScaler (the fp16 recipe): the rank without rows must still be able to step -- its scaler is initialised like the others'
+    scaler = torch.amp.GradScaler("cpu")
+    loss, _ = ddsp.train_step(model, ddsp.MSSLoss((128, 64)), opt, {k: v[lo:hi] for k, v in full.items()}, scaler=scaler)
+    assert float(loss) == 0.0 and all(torch.equal(before[k], v) for k, v in model.state_dict().items())
 
 
 @pytest.mark.gpu
@@ -450,11 +454,14 @@ def test_decoder_gradients_match_reference_autograd_fixture():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("amp_dtype", [torch.bfloat16])
+@pytest.mark.parametrize("amp_dtype", [torch.bfloat16, torch.float16])
 def test_train_step_autocast_gemms_track_fp32(amp_dtype):
-    """`train_step(..., amp_dtype=...)` (the reference's precision=16, train/train.py:50): only the dense layers' GEMMs run in the
-    low-precision type; synthesis, recurrence, fused passes, loss and the optimiser stay fp32.  The loss and every gradient
-    must track the fp32 step at that type's tolerance (cosine >= 0.99 for the big tensors), parameters stay fp32."""
+    """`train_step(..., amp_dtype=...)` (the reference's precision=16 = fp16 autocast + GradScaler, train/train.py:50; bf16 is this
+    package's faster, narrower-mantissa alternative): only the dense layers' GEMMs run in the low-precision type; synthesis,
+    recurrence, fused passes, loss and the optimiser stay fp32.  The loss and every gradient must track the fp32 step at that
+    type's tolerance (cosine >= 0.99 for the big tensors), parameters stay fp32.  fp16 runs the way Lightning runs it: a
+    GradScaler whose first steps overflow and back the scale off (steps skipped); the gradients compared are those of the
+    first step the scaler accepts, after its unscale."""
     class Conf:
         n_harmonics, n_noise_filters, sample_rate, hop_length = 100, 65, 16000, 128
         decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 256, 2, 128, 1
@@ -471,15 +478,20 @@ def test_train_step_autocast_gemms_track_fp32(amp_dtype):
         torch.manual_seed(9)
         model = ddsp.Decoder(Conf, noise_rng="device", seed=3).cuda()
         opt = torch.optim.SGD(model.parameters(), lr=0.0)          # lr 0: keep the gradients, leave the weights
-        scaler = None
-        loss, _ = ddsp.train_step(model, loss_fn, opt, batch, amp_dtype=amp, scaler=scaler)
-        scale = scaler.get_scale() if scaler is not None else 1.0
+        scaler = torch.amp.GradScaler("cuda") if amp is torch.float16 else None
+        for attempt in range(24):                                  # fp16: the default scale (65536) overflows at first and halves
+            model.noise.reseed(3)                                  # the same draw on every attempt (and as the fp32 step)
+            loss, _ = ddsp.train_step(model, loss_fn, opt, batch, amp_dtype=amp, scaler=scaler)
+            # (GradScaler.step has already unscaled the gradients in place; a skipped step leaves inf / nan in them)
+            if all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.requires_grad):
+                break
+            assert scaler is not None, "non-finite gradients without a scaler"
         assert all(p.dtype == torch.float32 and p.grad.dtype == torch.float32 for p in model.parameters() if p.requires_grad)
-        # (GradScaler.step has already unscaled the gradients in place)
-        return float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.requires_grad}, scale
+        return float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.requires_grad}, attempt
 
     l32, g32, _ = one(None)
-    l16, g16, _ = one(amp_dtype)
+    l16, g16, skipped = one(amp_dtype)
+    assert skipped < 23, "the scaler never found a scale whose gradients are finite"
     assert np.isfinite(l16) and abs(l16 - l32) <= 2e-2 * abs(l32)
     for n, g in g32.items():
         h = g16[n]
@@ -610,7 +622,8 @@ def test_colsum_kernel_equals_torch_sum(dtype):
 
 @pytest.mark.gpu
 def test_lowp_weight_copies_are_never_stale():
-    """dense.LowpWeights: a copy is handed out only while the parameter is unchanged since the refresh."""
+    """dense.LowpWeights: a copy is handed out only inside a refresh..release window and while the parameter is what it was
+    at the refresh; refresh() always re-copies (writes through `.data` and graph replays do not bump `_version`)."""
     from ddsp_pytorch_amd import dense
     w = nn.Parameter(torch.randn(8, 8, device="cuda"))
     cache = dense.LowpWeights()
@@ -624,6 +637,20 @@ def test_lowp_weight_copies_are_never_stale():
     cache.refresh(torch.bfloat16)
     assert torch.equal(cache.get(w, torch.bfloat16), w.detach().bfloat16())
     assert cache.get(w, torch.float16) is None
+    # a write through .data leaves _version alone (weight clipping, an EMA swap): the next refresh must still pick it up ...
+    v = w._version
+    w.data.mul_(0.5)
+    assert w._version == v
+    cache.refresh(torch.bfloat16)
+    assert torch.equal(cache.get(w, torch.bfloat16), w.detach().bfloat16())
+    # ... a swapped storage invalidates the copy at once ...
+    w.data = torch.randn(8, 8, device="cuda")
+    assert cache.get(w, torch.bfloat16) is None
+    # ... and outside a step's window nothing is handed out at all
+    cache.refresh(torch.bfloat16)
+    assert cache.get(w, torch.bfloat16) is not None
+    cache.release()
+    assert cache.get(w, torch.bfloat16) is None
 
 
 @pytest.mark.gpu
@@ -661,3 +688,9 @@ def test_graphed_train_step_equals_eager_steps(amp_dtype):
     for (k, a), (_, b) in zip(m_e.named_parameters(), m_g.named_parameters()):
         assert float((a - b).abs().max()) <= tol * max(1e-3, float(a.abs().max())), k
     assert m_g.noise.counter is None and int(graphed.counters[0].item()) == 4 * m_g.noise.draws(3, 40) == m_e.noise._offset
+    # the module's host-side offset followed the device counter: an eager forward after the graphed steps continues the stream
+    # (same draw as the eager model's next call) instead of replaying the first step's noise
+    assert m_g.noise._offset == m_e.noise._offset
+    with torch.no_grad():
+        h = {"H": torch.rand(3, 40, 9, device="cuda")}
+        assert torch.equal(m_g.noise(h), m_e.noise(h))

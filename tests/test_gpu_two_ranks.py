@@ -5,6 +5,12 @@ both on cuda:0, gloo rendezvous on 127.0.0.1 -- the one-GPU rehearsal of `bench.
   * data-parallel training: replicas stay bit-identical after two `train_step`s with one flat gradient all-reduce, and equal
     the single-process step on the whole batch (mean-reduced loss: the mean of equal shards' gradients is the batch gradient);
   * `python bench.py --gpus 2` without a launcher starts its own ranks and prints one JSON line with n_gpus = 2.
+
+Limitation (GRU section): both ranks share ONE GPU here, and each launches the persistent GRU recurrence, whose grid must
+be co-resident.  The in-process guard (occupancy check + per-device event gate) does not reach across processes; if the
+driver ever failed to co-schedule the two grids a rank would run into the 2 s spin bound.  The workers therefore run with
+DDSP_GRU_DEBUG=1: such a time-out raises DdspHipError naming the cause, instead of a NaN / bit-equality assertion far away.
+On real multi-GPU runs every rank owns its GPU and the situation does not arise.
 """
 import json
 import os
@@ -36,7 +42,7 @@ def _run_ranks(out_dir, world=2):
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1", DDSP_GRU_DEBUG="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_rank_worker.py"), str(out_dir)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
@@ -128,3 +134,25 @@ def test_bench_self_launches_two_ranks():
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
     assert line["value"] > 0 and abs(line["samples_per_sec_per_gpu"] * 2 - line["value"]) <= 1e-6 * line["value"]
     assert "roofline" in line and "cpu_baseline" not in line      # the CPU baseline is an N = 1 figure
+    # the N > 1 line diagnoses itself: every rank's own clock and per-kernel averages, the slowest rank by index, the
+    # collective backend and how many ranks its communicator holds (the driver's runs say "nccl" = RCCL here)
+    assert len(line["per_rank_ms"]) == 2 and all(v > 0 for v in line["per_rank_ms"])
+    assert line["slowest_rank"] in (0, 1) and line["per_rank_ms"][line["slowest_rank"]] == max(line["per_rank_ms"])
+    assert line["ms_per_step"] >= max(line["per_rank_ms"]) * (1 - 1e-6)          # the MAX over the ranks' clocks
+    assert set(line["per_rank_kernel_ms"]) == {"osc_frame_totals", "osc_scan", "osc_frame_synth", "noise_frame"}
+    assert all(len(v) == 2 and all(t > 0 for t in v) for v in line["per_rank_kernel_ms"].values())
+    assert line["rccl_ranks"] == 2 and line["collective_backend"] == "gloo"
+    assert "configs" not in line                                   # the secondary configurations are an N = 1 figure too
+
+
+def test_bench_train_mode_two_ranks_times_the_allreduce():
+    """bench.py --mode train --gpus 2: the line carries the gradient all-reduce timed on its own (allreduce_ms, the 19.35 MB
+    flat bucket at the full model; a small model here) and the per-rank step times."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["DDSP_GRU_DEBUG"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--backend", "gloo", "--one-device"], env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    line = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")][0]
+    assert line["n_gpus"] == 2 and line["allreduce_ms"] > 0 and line["config"]["allreduce_bytes"] > 0
+    assert len(line["per_rank_ms"]) == 2 and len(line["per_rank_allreduce_ms"]) == 2 and line["rccl_ranks"] == 2

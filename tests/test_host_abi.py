@@ -35,7 +35,7 @@ def test_header_symbols_exported():
 
 def test_abi_version_and_scratch_size():
     L = ddsp._lib.lib()
-    assert L.ddsp_hip_abi_version() == 1
+    assert L.ddsp_hip_abi_version() == 2 == ddsp._lib.ABI_VERSION
     assert L.ddsp_osc_scratch_bytes(0, 1, 1) == 0
     n = 64 * 500 * 100
     assert L.ddsp_osc_scratch_bytes(64, 500, 100) >= 16 * n
@@ -105,3 +105,20 @@ def test_synthetic_controls_ranges():
     assert ctl["c"].min() >= 1e-7 and ctl["c"].max() <= 2.0 + 1e-6
     mus = syn.make_controls(syn.CFG2, 1003, "musical", batch=2)["f0"]
     assert 31.0 < mus.min() and mus.max() < 2006.0
+
+
+def test_hooks_are_refused_without_opt_in():
+    """The process-global *_set_* hooks change every later launch: a process that did not set DDSP_TEST_HOOKS=1 before the
+    library was loaded gets DDSP_EPERM (-3) and nothing changes; restoring the default (0) is always allowed."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; L = ctypes.CDLL(sys.argv[1]); "
+            "print(L.ddsp_test_hooks_enabled(), L.ddsp_osc_set_tiling(13), L.ddsp_osc_set_tiling(0), L.ddsp_noise_set_generic(1), "
+            "L.ddsp_noise_set_generic(0), L.ddsp_gru_set_mode(2), L.ddsp_gru_set_mode(0), L.ddsp_gru_set_fault_step(3))")
+    env = {k: v for k, v in os.environ.items() if k != "DDSP_TEST_HOOKS"}
+    out = subprocess.run([sys.executable, "-c", code, ddsp._lib.SO_PATH], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["0", "-3", "0", "-3", "0", "-3", "0", "-3"], out
+    env["DDSP_TEST_HOOKS"] = "1"
+    out = subprocess.run([sys.executable, "-c", code, ddsp._lib.SO_PATH], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["1", "0", "0", "0", "0", "0", "0", "0"], out
+    assert ddsp._lib.lib().ddsp_test_hooks_enabled() == 1          # this process: tests/conftest.py opted in

@@ -1,4 +1,5 @@
 """Recurrence only: groups kept on one XCD (mode 0, default) vs dealt over all XCDs (mode 1)."""
+import os as _os; _os.environ.setdefault("DDSP_TEST_HOOKS", "1")  # kernel-form / tiling hooks (include/ddsp_hip.h)
 import sys, time, torch
 sys.path.insert(0, '.')
 from ddsp_pytorch_amd import gru as G, _lib

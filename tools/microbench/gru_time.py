@@ -1,4 +1,5 @@
 """Controller GRU: stock nn.GRU (MIOpen) vs the persistent HIP recurrence, forward and forward+backward."""
+import os as _os; _os.environ.setdefault("DDSP_TEST_HOOKS", "1")  # kernel-form / tiling hooks (include/ddsp_hip.h)
 import sys, time, torch, torch.nn as nn
 sys.path.insert(0, '.')
 import ddsp_pytorch_amd as ddsp

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A few launches of the filtered-noise forward at one shape, for rocprofv3 (kernel trace / PMC passes).
 usage: noise_prof.py B T hop F [mode]"""
+import os as _os; _os.environ.setdefault("DDSP_TEST_HOOKS", "1")  # kernel-form / tiling hooks (include/ddsp_hip.h)
 import os
 import sys
 

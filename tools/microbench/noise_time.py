@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Device time of the filtered-noise forward per shape: default path (in-LDS FFT form for hop 256 / 512) against the direct
 batched kernels (ddsp_noise_set_generic(2)).  HIP-event timing from the library's own profile hooks."""
+import os as _os; _os.environ.setdefault("DDSP_TEST_HOOKS", "1")  # kernel-form / tiling hooks (include/ddsp_hip.h)
 import json
 import os
 import sys

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Oscillator forward per harmonics-per-lane tiling K (ddsp_osc_set_tiling) at the BASELINE.json shapes: device ms of the
 totals and synth kernels from the library's HIP-event hooks.  usage: osc_tiling.py [cfg3|cfg4]"""
+import os as _os; _os.environ.setdefault("DDSP_TEST_HOOKS", "1")  # kernel-form / tiling hooks (include/ddsp_hip.h)
 import json
 import os
 import sys
