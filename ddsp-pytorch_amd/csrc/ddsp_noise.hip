@@ -587,6 +587,11 @@ int noise_forward_impl(const float *Hmag, const float *uniform, float *y, int B,
         hipError_t fe = hipSuccess;
         if (launch_noise_fft(p, s, (mode & 4) != 0, &fe)) return (int)fe;
     }
+    // hop 128 / 65 bands (the 16 kHz configurations): the wavefront-private form (ddsp_noise_wave.hip); mode bit 3 keeps the batched kernel
+    if (!(mode & (1 | 8))) {
+        hipError_t we = hipSuccess;
+        if (launch_noise_wave(p, s, &we)) return (int)we;
+    }
     const int lpf_log = pick_lpf_log(F, hop, mode);
     // (the batched kernel stores whole float4s: an output buffer that is not 16-byte aligned takes the generic kernel)
     if (!(mode & 1) && hop % 8 == 0 && lpf_log >= 0 && ((uintptr_t)y % 16) == 0) {

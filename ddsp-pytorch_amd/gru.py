@@ -43,6 +43,8 @@ def _ptr(t):
 
 
 def _raise_on_timeout(scratches, what: str) -> None:
+    if torch.cuda.is_current_stream_capturing():
+        return       # a status read is a synchronising copy: not capturable (a hipGraph's launches stay loud through their NaN outputs)
     for s in scratches:
         if gru_status(s) != 0:
             raise _lib.DdspHipError(

@@ -117,6 +117,7 @@ int ddsp_osc_set_tiling(int harmonics_per_lane);
 /* Test / tuning hook (process-global, read once per launch): bit 0 forces the generic one-frame-per-workgroup noise kernels
  * (any hop) instead of the batched ones (hop % 8 == 0, tile fits LDS); bit 1 keeps the direct (time-domain) forms where the
  * in-LDS FFT form would run (hop 512 with 2(F-1) <= hop); bit 2 takes the FFT form for hop 256 too (correct, not faster);
+ * bit 3 keeps the batched kernel where the wavefront-private form would run (hop 128, 65 bands);
  * (l + 1) << 8 forces 64 >> l frames per workgroup in the batched forward kernel (l = 0..3); 0 restores the defaults.
  * Same results within rounding. */
 int ddsp_noise_set_generic(int on);

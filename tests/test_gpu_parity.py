@@ -174,7 +174,7 @@ def test_noise_device_rng_statistics_and_accumulate():
 
 # ---- the in-kernel draw (rng='device', what bench.py times) against the oracle's Philox4x32-10 restatement -------------
 # (the oracle's generator is pinned by the Random123 known-answer vectors: tests/test_oracle_golden.py)
-FORMS = {"batched": (0, 128), "generic": (1, 128), "generic_ragged_hop": (1, 6), "batched_hop512": (2, 512), "fft": (0, 512), "fft_hop256": (4, 256)}
+FORMS = {"wave": (0, 128), "batched": (8, 128), "batched_hop64": (0, 64), "generic": (1, 128), "generic_ragged_hop": (1, 6), "batched_hop512": (2, 512), "fft": (0, 512), "fft_hop256": (4, 256)}
 
 
 @pytest.mark.parametrize("form", sorted(FORMS))
@@ -202,7 +202,7 @@ def test_noise_device_draw_is_the_oracles_philox_stream(form, seed, offset):
         assert np.max(np.abs(y[0, :4] - want)) <= (2e-6 if form.startswith("fft") else 0.0)
 
 
-@pytest.mark.parametrize("hop,nf,mode", [(128, 65, 0), (128, 65, 1), (64, 65, 0), (512, 257, 0), (512, 257, 2), (512, 195, 0), (256, 129, 0), (256, 129, 4), (24, 7, 0)])
+@pytest.mark.parametrize("hop,nf,mode", [(128, 65, 0), (128, 65, 8), (128, 65, 1), (64, 65, 0), (512, 257, 0), (512, 257, 2), (512, 195, 0), (256, 129, 0), (256, 129, 4), (24, 7, 0)])
 def test_noise_device_rng_vs_oracle(hop, nf, mode):
     """Real filters with the in-kernel draw, every kernel form: the oracle regenerates the same Philox stream (seed, offset)."""
     rng = np.random.default_rng(hop * 3 + nf)
@@ -249,7 +249,7 @@ def test_cpu_tensors_fail_loudly():
         ddsp.osc_forward(torch.from_numpy(g["f0"]), torch.from_numpy(g["c"]), torch.from_numpy(g["a"]), 64, 16000)
 
 
-@pytest.mark.parametrize("mode", [1, 2])     # 1: one frame per workgroup; 2: batched direct form where the FFT form would run
+@pytest.mark.parametrize("mode", [1, 2, 8])  # 1: one frame per workgroup; 2: batched direct form where the FFT form would run; 8: batched where the wavefront-private form would
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "g8_noise_*.npz"))))
 def test_noise_generic_kernel(path, mode):
     g = load_golden(os.path.basename(path)[:-4])
@@ -281,6 +281,33 @@ def test_noise_vs_oracle_ragged_tiles(hop, nf, B, T):
         finally:
             L.ddsp_noise_set_generic(0)
         assert np.max(np.abs(y.cpu().numpy() - ref)) <= 2e-6
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 15), (1, 16), (1, 17), (3, 11), (2, 500), (37, 3)])
+@pytest.mark.parametrize("injected", [True, False])
+def test_noise_wave_form_ragged_groups_vs_oracle(B, T, injected):
+    """The wavefront-private hop-128 / 65-band form (16 frames per wavefront-iteration, persistent): frame counts around the
+    group size, a long row, many short rows; injected draw and in-kernel draw; plain and accumulating; against the oracle and
+    (same draw) against the batched kernel it replaces."""
+    rng = np.random.default_rng(1000 * B + T)
+    Hn = syn.controller_range(rng.standard_normal((B, T, 65), dtype=np.float32))
+    u = rng.random((B, T, 128), dtype=np.float32) if injected else None
+    seed, offset = 4242, (3 << 32) + 9
+    kw = dict(uniform=dev(u)) if injected else dict(seed=seed, offset=offset)
+    ref = oracle.noise_forward(Hn, u, 128, seed=seed, offset=offset)
+    y = ddsp.noise_forward(dev(Hn), 128, **kw)
+    assert np.max(np.abs(y.cpu().numpy() - ref)) <= 2e-6
+    base = torch.randn(B, T * 128, device="cuda")
+    acc = ddsp.noise_forward(dev(Hn), 128, out=base.clone(), accumulate=True, **kw)
+    assert float((acc - (base + y)).abs().max()) <= 1e-6
+    L = ddsp._lib.lib()
+    L.ddsp_noise_set_generic(8)
+    try:
+        old = ddsp.noise_forward(dev(Hn), 128, **kw)
+    finally:
+        L.ddsp_noise_set_generic(0)
+    assert float((old - y).abs().max()) <= 2e-6
+    assert torch.equal(y, ddsp.noise_forward(dev(Hn), 128, **kw))            # deterministic
 
 
 @pytest.mark.parametrize("hop,nf", [(512, 257), (512, 195), (256, 129), (256, 100)])
