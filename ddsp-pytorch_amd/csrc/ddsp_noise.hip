@@ -590,7 +590,19 @@ int noise_forward_impl(const float *Hmag, const float *uniform, float *y, int B,
     // hop 128 / 65 bands (the 16 kHz configurations): the wavefront-private form (ddsp_noise_wave.hip); mode bit 3 keeps the batched kernel
     if (!(mode & (1 | 8))) {
         hipError_t we = hipSuccess;
-        if (launch_noise_wave(p, s, &we)) return (int)we;
+        const long done = launch_noise_wave(p, s, &we);
+        if (done < 0) return (int)we;
+        if (done == (long)B * T) return 0;
+        if (done > 0) {                                       // a remainder of fewer than 16 frames: the kernels below, same counters
+            p.Hm += done * F;
+            if (p.u) p.u += done * hop;
+            p.y += done * hop;
+            p.offset += (uint64_t)done * (uint64_t)((hop + 3) / 4);
+            B = 1;
+            T = (int)((long)p.B * p.T - done);
+            p.B = B;
+            p.T = T;
+        }
     }
     const int lpf_log = pick_lpf_log(F, hop, mode);
     // (the batched kernel stores whole float4s: an output buffer that is not 16-byte aligned takes the generic kernel)
