@@ -249,8 +249,13 @@ struct FrameSrc {
 // ---- the kernel ------------------------------------------------------------------------------------------------
 // R1 = N / 64 = R / 32 (16: hop 512, 8: hop 256).  IRFFT: S == 512, impulse responses by one packed 512-point inverse
 // FFT; otherwise direct cosine sums (any even S <= R).
-template <int R1, bool IRFFT>
-__global__ void __launch_bounds__(64) noise_fft_kernel(NoiseParams p, long npairs)
+// ACC: add to the output buffer's contents (harmonics + noise, decoder.py:132).
+// Software pipeline over the frame pairs (round 3): the NEXT pair's filter magnitudes (IRFFT) and THIS pair's output lines (ACC)
+// are read at the top of a pair's work and used a whole pair later / at its end -- an HBM read takes ~8000 cycles under this
+// kernel's own load, two thirds of a pair's time -- and every global access sits in straight-line code, so that the compiler's
+// vmcnt waits are counts, not drains.  An odd last frame is paired with itself (both halves compute and store the same values).
+template <int R1, bool IRFFT, bool ACC>
+__global__ void __launch_bounds__(64, 2) noise_fft_kernel(NoiseParams p, long npairs)
 {
     constexpr int N = 64 * R1, R = N / 2;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -285,22 +290,49 @@ __global__ void __launch_bounds__(64) noise_fft_kernel(NoiseParams p, long npair
     const uint64_t base_off = p.offset + (p.offset_dev ? *p.offset_dev : 0ull);
     constexpr int quads = R >> 2;
 
-    for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+    // the packed, Hermitian-extended spectra of a pair: h[n1] = (Ha[src], Hb[src]), bin f = 64 n1 + lane, src = f <= 256 ? f : 512 - f
+    struct Mags { float a[8], b[8]; };
+    auto load_mags = [&](long pr) {
+        const long fa = 2 * pr, fb = (2 * pr + 1 < nframes) ? 2 * pr + 1 : 2 * pr;
+        const float *Ha = p.Hm + fa * F, *Hb = p.Hm + fb * F;
+        Mags m;
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) {
+            const int f = 64 * n1 + lane;
+            const int src = f <= 256 ? f : 512 - f;
+            m.a[n1] = Ha[src];
+            m.b[n1] = Hb[src];
+        }
+        return m;
+    };
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    struct Lines { v4 v[2][R / 256]; };
+
+    long pair = blockIdx.x;
+    if (pair >= npairs) return;
+    Mags hcur;
+    if (IRFFT) hcur = load_mags(pair);
+    for (;;) {
         FrameSrc fr[2];
         fr[0].frame = 2 * pair;     fr[0].valid = true;
-        fr[1].frame = 2 * pair + 1; fr[1].valid = fr[1].frame < nframes;
+        fr[1].frame = (2 * pair + 1 < nframes) ? 2 * pair + 1 : 2 * pair;   // an odd last frame is paired with itself
+        fr[1].valid = true;
+        const long next = pair + gridDim.x;
+        Lines yv;
+        if (ACC) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < R / 256; ++e) yv.v[q][e] = reinterpret_cast<const v4 *>(p.y + fr[q].frame * R)[lane + 64 * e];
+        }
+        Mags hnext;
+        if (IRFFT) hnext = load_mags(next < npairs ? next : pair);            // (the last pair re-reads its own: no branch around the loads)
 
         // ---- 1. impulse responses -> kk[j] = k_a[j] + i k_b[j] in bufB[0, R) ----------------------------------
         cf h[8];
         if (IRFFT) {
-            const float *Ha = p.Hm + fr[0].frame * F;
-            const float *Hb = p.Hm + (fr[1].valid ? fr[1].frame : fr[0].frame) * F;
 #pragma unroll
-            for (int n1 = 0; n1 < 8; ++n1) {
-                const int f = 64 * n1 + lane;
-                const int src = f <= 256 ? f : 512 - f;          // Hermitian extension of the real, zero-phase spectrum
-                h[n1] = make_float2(Ha[src], fr[1].valid ? Hb[src] : 0.0f);
-            }
+            for (int n1 = 0; n1 < 8; ++n1) h[n1] = make_float2(hcur.a[n1], hcur.b[n1]);
         }
         if (IRFFT) {
             fft_wave<8, true, false>(h, tw8, bufB, lane);
@@ -469,22 +501,27 @@ __global__ void __launch_bounds__(64) noise_fft_kernel(NoiseParams p, long npair
                 yb[n] = v[d * 8 + k3].y * kScale;
             }
         DDSP_WAVE_ORDER();
+        // the next pair's magnitudes change registers HERE, before this pair's stores are issued: their loads are a whole pair old
+        // (complete), whereas a wait placed after the stores -- where the compiler would sink these copies -- drains the stores too
+        if (IRFFT) {
+            hcur = hnext;
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) { asm volatile("" : "+v"(hcur.a[n1])); asm volatile("" : "+v"(hcur.b[n1])); }
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            if (!fr[q].valid) continue;
-            float4 *dst = reinterpret_cast<float4 *>(p.y + fr[q].frame * R);
-            const float4 *src = reinterpret_cast<const float4 *>(q ? yb : ya);
+            v4 *dst = reinterpret_cast<v4 *>(p.y + fr[q].frame * R);
+            const v4 *src = reinterpret_cast<const v4 *>(q ? yb : ya);
 #pragma unroll
             for (int e = 0; e < R / 256; ++e) {
-                float4 o = src[lane + 64 * e];
-                if (p.accumulate) {
-                    const float4 a = dst[lane + 64 * e];
-                    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-                }
+                v4 o = src[lane + 64 * e];
+                if (ACC) o += yv.v[q][e];
                 dst[lane + 64 * e] = o;
             }
         }
         DDSP_WAVE_ORDER();
+        if (next >= npairs) break;
+        pair = next;
     }
 }
 
@@ -514,7 +551,8 @@ hipError_t launch(const NoiseParams &p, hipStream_t s)
     const long resident = (long)cus * per_cu;
     const long grid = npairs < resident ? npairs : resident;
     const int slot = ddsp_prof::begin(ddsp_prof::NOISE, s);
-    hipLaunchKernelGGL((noise_fft_kernel<R1, IRFFT>), dim3((unsigned)grid), dim3(64), lds, s, p, npairs);
+    if (p.accumulate) hipLaunchKernelGGL((noise_fft_kernel<R1, IRFFT, true>), dim3((unsigned)grid), dim3(64), lds, s, p, npairs);
+    else hipLaunchKernelGGL((noise_fft_kernel<R1, IRFFT, false>), dim3((unsigned)grid), dim3(64), lds, s, p, npairs);
     ddsp_prof::end(slot, s);
     return hipGetLastError();
 }
