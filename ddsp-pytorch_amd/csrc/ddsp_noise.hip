@@ -683,6 +683,10 @@ static int noise_backward_impl(const float *grad_y, const float *uniform, float 
     p.B = B; p.T = T; p.F = F; p.R = hop; p.S = 2 * (F - 1);
     p.seed = seed; p.offset = offset; p.offset_dev = offset_dev;
     hipStream_t s = (hipStream_t)stream;
+    if (!(g_force_generic.load(std::memory_order_relaxed) & 3)) {    // hop 512: correlation in the in-LDS FFT form (mode bits 0 / 1 keep the direct forms)
+        hipError_t fe = hipSuccess;
+        if (launch_noise_fft_backward(grad_y, uniform, grad_H, B, T, F, hop, seed, offset, offset_dev, s, &fe)) return (int)fe;
+    }
     const int lpf_log = pick_bwd_lpf_log(F, hop);
     p.lpf_log = lpf_log < 0 ? 0 : lpf_log;
     if (!(g_force_generic.load(std::memory_order_relaxed) & 1) && hop % 8 == 0 && lpf_log >= 0) {

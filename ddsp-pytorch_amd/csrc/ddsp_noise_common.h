@@ -43,6 +43,11 @@ __device__ __forceinline__ float philox_to_sample(uint32_t r) { return (float)(r
 // returns false (and launches nothing) otherwise.  *err receives the launch status.
 bool launch_noise_fft(const NoiseParams &p, hipStream_t s, bool force_fft, hipError_t *err);
 
+// Backward of the noise path in the in-LDS FFT form (hop 512, impulse response not cropped); returns false (and launches
+// nothing) for other shapes.  *err receives the launch status.
+bool launch_noise_fft_backward(const float *grad_y, const float *uniform, float *grad_H, int B, int T, int F, int hop, uint64_t seed,
+                               uint64_t offset, const uint64_t *offset_dev, hipStream_t s, hipError_t *err);
+
 // Launches the wavefront-private hop-128 / 65-band form (ddsp_noise_wave.hip) on the leading whole groups of 16 frames when the
 // shape is the one it is built for.  Returns the number of frames it took (0: not its shape, nothing launched; the caller runs
 // the remaining frames -- fewer than 16 -- through another kernel, with the Philox offset advanced), -1 on a launch error (*err).

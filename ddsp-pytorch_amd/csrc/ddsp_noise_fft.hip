@@ -525,6 +525,162 @@ __global__ void __launch_bounds__(64, 2) noise_fft_kernel(NoiseParams p, long np
     }
 }
 
+// =====================================================================================================================
+// Backward w.r.t. the filter magnitudes at hop 512 (autograd of filtered_noise.py:7-32; the draw is a constant of the graph),
+// the mirror of the forward above, again one wavefront per frame pair and no workgroup barrier:
+//   y[n] = sum_{m<=n} x[m] kern[n-m]   =>   d/dkern[j] = sum_d x[d] g[j+d]: a correlation, conj(X) G in the spectrum.
+//   1. the SAME noise (Philox counters or the injected draw) -> xx = x_a + i x_b; the upstream gradient rows -> gg = g_a + i g_b
+//   2. two N-point FFTs (N = 2R, inputs zero above R), natural order in LDS
+//   3. per bin, with A = Cx[g], B = conj Cx[N-g], E = Cg[g], F = conj Cg[N-g]:
+//         P[g] = [conj(A + B)(E + F) + i conj(A - B)(E - F)] / 4 = conj(X_a) G_a + i conj(X_b) G_b
+//      and ONE inverse FFT gives dk_a + i dk_b; the first R lags are the taps' gradients
+//   4. dz[n] = dk[n] window(n) lands exactly in the register layout a 512-point transform takes as input;
+//      dH_k = c_k / S Re FFT_S(dz)[k] (z = irfft(H) is a cosine transform of the real, zero-phase H), both frames from ONE
+//      packed transform: Re Z_a[k] = (Re Z[k] + Re Z[S-k]) / 2, Re Z_b[k] = (Im Z[k] + Im Z[S-k]) / 2.
+// Only S == R = 512 (257 bands, BASELINE.json configs[2]).  Shorter impulse responses (195 bands, the reference's default) stay on
+// the direct kernels: their dH step is F x S/2 cosine sums per frame either way, and a built and measured wavefront-per-pair
+// version of it was slower than the lane-per-frame batched kernel (1.94 vs 1.36 ms at batch 512 x 375).
+struct NoiseFftBwdParams {
+    const float *g;      // [B, T*R] upstream gradient
+    const float *u;      // [B, T, R] the forward's uniform draw (nullable -> Philox from seed / offset, as the forward)
+    float *gH;           // [B, T, F]
+    int B, T, F, S;
+    uint64_t seed, offset;
+    const uint64_t *offset_dev;
+};
+
+__global__ void __launch_bounds__(64, 2) noise_fft_bwd_kernel(NoiseFftBwdParams p, long npairs)
+{
+    constexpr int R1 = 16, N = 64 * R1, R = N / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    constexpr int NB = buf_elems<R1>();
+    cf *bufA = reinterpret_cast<cf *>(smem_f);
+    cf *bufB = bufA + NB;
+    const int lane = threadIdx.x;
+    const int F = p.F;                                   // 257: S = 2 (F - 1) = R
+    const long nframes = (long)p.B * p.T;
+
+    Twiddles<R1> tw;
+    make_twiddles<R1>(tw, lane);
+    Twiddles<8> tw8;
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) tw8.t1[k1] = tw.t1[(R1 / 8) * k1];
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+        float sn, cs;
+        sincospif(2.0f * (float)(((lane >> 3) * k2) & 63) / 64.0f, &sn, &cs);
+        tw8.t2[0][k2] = make_float2(cs, -sn);
+    }
+    const float win_c = tw.t1[(R1 / 8) * 1].x, win_s = -tw.t1[(R1 / 8) * 1].y;     // cos, sin of 2 pi lane / 512
+    DDSP_WAVE_ORDER();
+    const uint64_t base_off = p.offset + (p.offset_dev ? *p.offset_dev : 0ull);
+    constexpr int quads = R >> 2;
+
+    for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+        const long fa = 2 * pair, fb = (2 * pair + 1 < nframes) ? 2 * pair + 1 : 2 * pair;   // an odd last frame is paired with itself
+        // ---- 1. xx -> bufA[0, R), gg -> bufB[0, R) --------------------------------------------------------------------
+        {
+            const float *ga = p.g + fa * R, *gb = p.g + fb * R;
+#pragma unroll
+            for (int e = 0; e < quads / 64; ++e) {
+                const int q = lane + 64 * e;
+                const float4 a = *reinterpret_cast<const float4 *>(ga + 4 * q);
+                const float4 b = *reinterpret_cast<const float4 *>(gb + 4 * q);
+                bufB[4 * q + 0] = make_float2(a.x, b.x);
+                bufB[4 * q + 1] = make_float2(a.y, b.y);
+                bufB[4 * q + 2] = make_float2(a.z, b.z);
+                bufB[4 * q + 3] = make_float2(a.w, b.w);
+            }
+        }
+        if (p.u) {
+            const float *ua = p.u + fa * R, *ub = p.u + fb * R;
+#pragma unroll
+            for (int e = 0; e < quads / 64; ++e) {
+                const int q = lane + 64 * e;
+                const float4 a = *reinterpret_cast<const float4 *>(ua + 4 * q);
+                const float4 b = *reinterpret_cast<const float4 *>(ub + 4 * q);
+                bufA[4 * q + 0] = make_float2(a.x * 2.0f - 1.0f, b.x * 2.0f - 1.0f);
+                bufA[4 * q + 1] = make_float2(a.y * 2.0f - 1.0f, b.y * 2.0f - 1.0f);
+                bufA[4 * q + 2] = make_float2(a.z * 2.0f - 1.0f, b.z * 2.0f - 1.0f);
+                bufA[4 * q + 3] = make_float2(a.w * 2.0f - 1.0f, b.w * 2.0f - 1.0f);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < quads / 64; ++e) {
+                const int q = lane + 64 * e;
+                uint32_t ra[4], rb[4];
+                const uint64_t ca = base_off + (uint64_t)fa * (uint64_t)quads + (uint64_t)q;
+                const uint64_t cb = base_off + (uint64_t)fb * (uint64_t)quads + (uint64_t)q;
+                philox4x32_10((uint32_t)ca, (uint32_t)(ca >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32), ra);
+                philox4x32_10((uint32_t)cb, (uint32_t)(cb >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32), rb);
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) bufA[4 * q + c4] = make_float2(philox_to_sample(ra[c4]), philox_to_sample(rb[c4]));
+            }
+        }
+        DDSP_WAVE_ORDER();
+
+        // ---- 2. Cx = FFT_N(xx), Cg = FFT_N(gg), natural order in bufA / bufB ---------------------------------------------
+        cf v[R1];
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) v[n1] = (n1 < R1 / 2) ? bufA[64 * n1 + lane] : make_float2(0.0f, 0.0f);
+        DDSP_WAVE_ORDER();
+        fft_wave<R1, false, true>(v, tw, bufA, lane);
+        store_natural<R1>(v, bufA, lane);
+#pragma unroll
+        for (int n1 = 0; n1 < R1; ++n1) v[n1] = (n1 < R1 / 2) ? bufB[64 * n1 + lane] : make_float2(0.0f, 0.0f);
+        DDSP_WAVE_ORDER();
+        fft_wave<R1, false, true>(v, tw, bufB, lane);
+        store_natural<R1>(v, bufB, lane);
+        DDSP_WAVE_ORDER();
+
+        // ---- 3. split, correlate, re-pack; inverse FFT -----------------------------------------------------------------
+#pragma unroll
+        for (int g1 = 0; g1 < R1; ++g1) {
+            const int g = 64 * g1 + lane, gm = (g1 == 0) ? ((N - lane) & (N - 1)) : (N - lane) - 64 * g1;
+            const cf A = bufA[g], Bc = bufA[gm], E = bufB[g], Fc = bufB[gm];
+            const cf U = make_float2(A.x + Bc.x, A.y - Bc.y), W = make_float2(E.x + Fc.x, E.y - Fc.y);      // A + B, E + F
+            const cf U2 = make_float2(A.x - Bc.x, A.y + Bc.y), W2 = make_float2(E.x - Fc.x, E.y + Fc.y);    // A - B, E - F
+            const cf s1 = make_float2(__fmaf_rn(U.x, W.x, U.y * W.y), __fmaf_rn(U.x, W.y, -(U.y * W.x)));   // conj(U) W
+            const cf s2 = make_float2(__fmaf_rn(U2.x, W2.x, U2.y * W2.y), __fmaf_rn(U2.x, W2.y, -(U2.y * W2.x)));
+            v[g1] = make_float2(s1.x - s2.y, s1.y + s2.x);        // s1 + i s2; the 1/(4N) is applied below
+        }
+        DDSP_WAVE_ORDER();
+        fft_wave<R1, true, false>(v, tw, bufA, lane);
+        constexpr float kScale = 1.0f / (4.0f * (float)N);
+
+        {
+            // ---- 4. dz[n] = dk[n] window(n), n = lane + 64 (d + 2 k3): exactly input n1 = d + 2 k3 of the 512-point transform
+            constexpr float r8 = 0.70710678118654752f;
+            const float ck[8] = {1.0f, r8, 0.0f, -r8, -1.0f, -r8, 0.0f, r8}, sk[8] = {0.0f, r8, 1.0f, r8, 0.0f, -r8, -1.0f, -r8};
+            cf h[8];
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int k3 = 0; k3 < 4; ++k3) {
+                    const int n1 = d + 2 * k3;
+                    const float wgt = __fmaf_rn(0.5f, win_c * ck[n1] - win_s * sk[n1], 0.5f) * kScale;
+                    h[n1] = make_float2(v[d * 8 + k3].x * wgt, v[d * 8 + k3].y * wgt);
+                }
+            fft_wave<8, false, false>(h, tw8, bufB, lane);        // h[k3] = Z[lane + 64 k3]
+#pragma unroll
+            for (int k3 = 0; k3 < 8; ++k3) bufA[lane + 64 * k3] = h[k3];
+            DDSP_WAVE_ORDER();
+            float *Ha = p.gH + fa * F, *Hb = p.gH + fb * F;
+            constexpr float invS = 1.0f / 512.0f;
+#pragma unroll
+            for (int k3 = 0; k3 < 4; ++k3) {
+                const int k = lane + 64 * k3;
+                const cf zm = bufA[(512 - k) & 511];
+                const float cfac = (k == 0) ? 0.5f * invS : invS;
+                Ha[k] = (h[k3].x + zm.x) * cfac;
+                Hb[k] = (h[k3].y + zm.y) * cfac;
+            }
+            if (lane == 0) { Ha[256] = h[4].x * invS; Hb[256] = h[4].y * invS; }          // c_k / (2 S) (Z[256] + Z[256]) with c_k = 1
+        }
+        DDSP_WAVE_ORDER();
+    }
+}
+
 template <int R1, bool IRFFT>
 hipError_t launch(const NoiseParams &p, hipStream_t s)
 {
@@ -578,6 +734,34 @@ bool launch_noise_fft(const NoiseParams &p, hipStream_t s, bool force_fft, hipEr
         return true;
     }
     return false;
+}
+
+bool launch_noise_fft_backward(const float *grad_y, const float *uniform, float *grad_H, int B, int T, int F, int hop, uint64_t seed,
+                               uint64_t offset, const uint64_t *offset_dev, hipStream_t s, hipError_t *err)
+{
+    const int S = 2 * (F - 1);
+    if (hop != 512 || S != hop) return false;                        // other shapes: the direct kernels (see above)
+    if (((uintptr_t)grad_y % 16) != 0 || (uniform && ((uintptr_t)uniform % 16) != 0)) return false;
+    NoiseFftBwdParams q;
+    q.g = grad_y; q.u = uniform; q.gH = grad_H; q.B = B; q.T = T; q.F = F; q.S = S;
+    q.seed = seed; q.offset = offset; q.offset_dev = offset_dev;
+    const long nframes = (long)B * T, npairs = (nframes + 1) / 2;
+    const size_t lds = sizeof(float2) * 2 * buf_elems<16>();
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { *err = e; return true; }
+    static int cached[64] = {};
+    if (!cached[dev & 63]) {
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) { *err = e; return true; }
+        cached[dev & 63] = cus;
+    }
+    cus = cached[dev & 63];
+    const long resident = (long)cus * 8;                             // 17 KB of LDS each: eight wavefronts per CU
+    const long grid = npairs < resident ? npairs : resident;
+    hipLaunchKernelGGL(noise_fft_bwd_kernel, dim3((unsigned)grid), dim3(64), lds, s, q, npairs);
+    *err = hipGetLastError();
+    return true;
 }
 
 }  // namespace ddsp_noise

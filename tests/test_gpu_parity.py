@@ -351,8 +351,8 @@ def test_osc_grad_matches_reference_autograd():
     assert np.max(np.abs(ga - g["grad_a"])) <= 1e-5 * max(1.0, np.max(np.abs(g["grad_a"])))
 
 
-@pytest.mark.parametrize("name", ["g10_noise_grad_hop128", "g10_noise_grad_hop64"])
-@pytest.mark.parametrize("generic", [0, 1])
+@pytest.mark.parametrize("name", ["g10_noise_grad_hop128", "g10_noise_grad_hop64", "g17_noise_grad_hop512_f257", "g17_noise_grad_hop512_f195"])
+@pytest.mark.parametrize("generic", [0, 1, 2])   # 0: default kernels (hop 512: in-LDS FFT form); 1: one frame per workgroup; 2: batched direct form
 def test_noise_grad_matches_reference_autograd(name, generic):
     g = load_golden(name)
     hop = int(g["hop"])
@@ -367,6 +367,30 @@ def test_noise_grad_matches_reference_autograd(name, generic):
     assert np.max(np.abs(y.detach().cpu().numpy() - g["y"])) <= 2e-6
     ref = g["grad_H"]
     assert np.max(np.abs(H.grad.cpu().numpy() - ref)) <= 1e-5 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("nf", [257, 195])
+@pytest.mark.parametrize("injected", [False, True])
+def test_noise_fft_backward_equals_direct_backward(nf, injected):
+    """hop 512, 257 bands: the in-LDS FFT form of the backward (correlation as conj(X) G; dH from one packed 512-point
+    transform) against the direct (time-domain) backward on the same draw -- in-kernel Philox with a 64-bit offset, or
+    injected; 21 frames: the last frame pair is half empty.  (195 bands take the direct kernels either way: same results.)"""
+    rng = np.random.default_rng(900 + nf)
+    B, T, hop = 3, 7, 512
+    gy = dev(rng.standard_normal((B, T * hop)).astype(np.float32))
+    u = dev(rng.random((B, T, hop), dtype=np.float32)) if injected else None
+    kw = dict(uniform=u) if injected else dict(seed=31337, offset=(9 << 32) + 5)
+    L = ddsp._lib.lib()
+    got = ddsp.noise_backward(gy, hop, nf, **kw)
+    again = ddsp.noise_backward(gy, hop, nf, **kw)
+    L.ddsp_noise_set_generic(2)
+    try:
+        ref = ddsp.noise_backward(gy, hop, nf, **kw)
+    finally:
+        L.ddsp_noise_set_generic(0)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().max()) <= 1e-5 * scale
+    assert torch.equal(got, again)
 
 
 def test_osc_grad_vs_torch_restatement_bigger():

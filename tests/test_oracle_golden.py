@@ -184,3 +184,16 @@ def test_noise_oracle_regenerates_the_device_draw():
     H = rng.uniform(0.0, 2.0, (2, 3, 9)).astype(np.float32)
     u = oracle.philox_uniform(11, 5, 2, 3, 16)
     assert np.array_equal(oracle.noise_forward(H, None, 16, seed=11, offset=5), oracle.noise_forward(H, u, 16))
+
+
+@pytest.mark.parametrize("name", ["g10_noise_grad_hop128", "g10_noise_grad_hop64", "g17_noise_grad_hop512_f257", "g17_noise_grad_hop512_f195"])
+def test_torch_restatement_noise_gradient_equals_reference_autograd(name):
+    """The restatement's autograd d/dH (what several GPU tests use as their reference) against the reference's own, fixtures G10 / G17."""
+    import torch
+    from oracle import torch_restatement as tr
+    g = load_golden(name)
+    H = torch.from_numpy(g["H"]).requires_grad_()
+    y = tr.filtered_noise(H, int(g["hop"]), uniform=torch.from_numpy(g["uniform"]))
+    (y * torch.from_numpy(g["g"])).sum().backward()
+    assert np.array_equal(y.detach().numpy(), g["y"])
+    assert np.max(np.abs(H.grad.numpy() - g["grad_H"])) <= 1e-6 * max(1.0, float(np.max(np.abs(g["grad_H"]))))

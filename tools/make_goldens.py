@@ -417,9 +417,29 @@ def g16():
              grad_noise=rv.noise.grad.numpy(), grad_decay=rv.decay.grad.numpy(), grad_wet=rv.wet.grad.numpy())
     torch.set_grad_enabled(False)
 
+def g17():
+    """The reference's autograd d/dH of FilteredNoise at hop 512 (filtered_noise.py:25-32 through :7-22): 257 bands (the impulse
+    response fills the frame: the packed-FFT route of the HIP backward) and 195 bands (the reference's default, config/default.py:
+    S = 388 < hop, cosine-sum route); 3 x 5 frames so that the last frame pair is half empty."""
+    torch.set_grad_enabled(True)
+    rng = np.random.default_rng(170)
+    for nf in (257, 195):
+        hop = 512
+        H = syn.controller_range(rng.standard_normal((3, 5, nf), dtype=np.float32))
+        g = rng.standard_normal((3, 5 * hop)).astype(np.float32)
+        Ht = t(H).requires_grad_()
+        torch.manual_seed(1700 + nf)
+        y = RefNoise(Conf(1, 48000, hop))({"H": Ht})
+        torch.manual_seed(1700 + nf)
+        u = torch.rand(3, 5, hop).numpy()
+        (y * t(g)).sum().backward()
+        save(f"g17_noise_grad_hop512_f{nf}", hop=hop, H=H, g=g, uniform=u, y=y.detach().numpy(), grad_H=Ht.grad.numpy())
+    torch.set_grad_enabled(False)
+
+
 if __name__ == "__main__":
     print("torch", torch.__version__, "threads", torch.get_num_threads())
     only = sys.argv[1:]                                       # e.g. `make_goldens.py g16`: just the named generators
-    for fn in (g1, g2_g3_g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16):
+    for fn in (g1, g2_g3_g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16, g17):
         if not only or fn.__name__ in only:
             fn()
