@@ -576,22 +576,33 @@ __global__ void __launch_bounds__(64, 2) noise_fft_bwd_kernel(NoiseFftBwdParams 
     const uint64_t base_off = p.offset + (p.offset_dev ? *p.offset_dev : 0ull);
     constexpr int quads = R >> 2;
 
-    for (long pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
-        const long fa = 2 * pair, fb = (2 * pair + 1 < nframes) ? 2 * pair + 1 : 2 * pair;   // an odd last frame is paired with itself
-        // ---- 1. xx -> bufA[0, R), gg -> bufB[0, R) --------------------------------------------------------------------
-        {
-            const float *ga = p.g + fa * R, *gb = p.g + fb * R;
+    // the upstream gradient rows of a pair, read a whole pair ahead (as the forward does with its magnitudes)
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    struct Rows { v4 a[quads / 64], b[quads / 64]; };
+    auto load_rows = [&](long pr) {
+        const long ra = 2 * pr, rb = (2 * pr + 1 < nframes) ? 2 * pr + 1 : 2 * pr;
+        Rows r;
 #pragma unroll
-            for (int e = 0; e < quads / 64; ++e) {
-                const int q = lane + 64 * e;
-                const float4 a = *reinterpret_cast<const float4 *>(ga + 4 * q);
-                const float4 b = *reinterpret_cast<const float4 *>(gb + 4 * q);
-                bufB[4 * q + 0] = make_float2(a.x, b.x);
-                bufB[4 * q + 1] = make_float2(a.y, b.y);
-                bufB[4 * q + 2] = make_float2(a.z, b.z);
-                bufB[4 * q + 3] = make_float2(a.w, b.w);
-            }
+        for (int e = 0; e < quads / 64; ++e) {
+            r.a[e] = reinterpret_cast<const v4 *>(p.g + ra * R)[lane + 64 * e];
+            r.b[e] = reinterpret_cast<const v4 *>(p.g + rb * R)[lane + 64 * e];
         }
+        return r;
+    };
+    long pair = blockIdx.x;
+    if (pair >= npairs) return;
+    Rows gcur = load_rows(pair);
+    for (;;) {
+        const long fa = 2 * pair, fb = (2 * pair + 1 < nframes) ? 2 * pair + 1 : 2 * pair;   // an odd last frame is paired with itself
+        const long next = pair + gridDim.x;
+        // ---- 1. xx -> bufA[0, R), gg -> bufB[0, R) --------------------------------------------------------------------
+#pragma unroll
+        for (int e = 0; e < quads / 64; ++e) {
+            const int q = lane + 64 * e;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) bufB[4 * q + c4] = make_float2(gcur.a[e][c4], gcur.b[e][c4]);
+        }
+        const Rows gnext = load_rows(next < npairs ? next : pair);                 // (the last pair re-reads its own rows: no branch)
         if (p.u) {
             const float *ua = p.u + fa * R, *ub = p.u + fb * R;
 #pragma unroll
@@ -678,6 +689,9 @@ __global__ void __launch_bounds__(64, 2) noise_fft_bwd_kernel(NoiseFftBwdParams 
             if (lane == 0) { Ha[256] = h[4].x * invS; Hb[256] = h[4].y * invS; }          // c_k / (2 S) (Z[256] + Z[256]) with c_k = 1
         }
         DDSP_WAVE_ORDER();
+        if (next >= npairs) break;
+        gcur = gnext;
+        pair = next;
     }
 }
 
