@@ -17,7 +17,7 @@ constexpr int UNROLL = 16;
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-enum Op { MUL_LO, MUL_HI, MAD64, MUL24, XOR3, FMA32, MFMA16, MFMA32, MFMA16_FMA_SAME, MFMA16_ROLE_SPLIT, PHILOX, MFMA16_XOR_SAME, MFMA16_MAD64_SAME, MFMA16_DSREAD_SAME };
+enum Op { MUL_LO, MUL_HI, MAD64, MUL24, XOR3, FMA32, MFMA16, MFMA32, MFMA16_FMA_SAME, MFMA16_ROLE_SPLIT, PHILOX, MFMA16_XOR_SAME, MFMA16_MAD64_SAME, MFMA16_DSREAD_SAME, CVT_U32_F32, ADD_U32, TOTALS_F64, TOTALS_INT };
 
 __device__ __forceinline__ void philox(unsigned c0, unsigned c1, unsigned k0, unsigned k1, unsigned (&out)[4])
 {
@@ -88,6 +88,22 @@ __global__ void __launch_bounds__(256) rate_kernel(float *out, unsigned seed, un
             if (OP == FMA32) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[u]) : "v"(b), "v"(a));
             if (OP == MFMA16) acc4[u & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc4[u & 3], 0, 0, 0);
             if (OP == MFMA32) acc16[u & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc16[u & 1], 0, 0, 0);
+            if (OP == CVT_U32_F32) asm volatile("v_cvt_u32_f32 %0, %1" : "=v"(x[u]) : "v"(f[u]));
+            if (OP == ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[u]) : "v"(m));
+            if (OP == TOTALS_F64) {   // the oscillator's frame-totals chain: mul, fma, cvt f64, add f64
+                float t; double dd;
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(b), "v"(f[u]));
+                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(a), "v"(f[u]));
+                asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(dd) : "v"(t));
+                asm volatile("v_add_f64 %0, %0, %1" : "+v"(w[u]) : "v"(dd));
+            }
+            if (OP == TOTALS_INT) {   // the same with the increments pre-scaled to integers: mul, fma, cvt u32, add u32
+                float t; unsigned ti;
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(b), "v"(f[u]));
+                asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(a), "v"(f[u]));
+                asm volatile("v_cvt_u32_f32 %0, %1" : "=v"(ti) : "v"(t));
+                asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[u]) : "v"(ti));
+            }
             if (OP == MFMA16_XOR_SAME) {
                 acc4[u & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc4[u & 3], 0, 0, 0);
                 asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x[u]) : "v"(m));
@@ -166,6 +182,10 @@ int main()
     run<MFMA16>("v_mfma_f32_16x16x4_f32", UNROLL, dout);
     run<MFMA32>("v_mfma_f32_32x32x2_f32", UNROLL, dout);
     run<MFMA16_FMA_SAME>("mfma16x16x4 + 4 fma (same wave)", UNROLL, dout, "group");
+    run<CVT_U32_F32>("v_cvt_u32_f32", UNROLL, dout);
+    run<ADD_U32>("v_add_u32", UNROLL, dout);
+    run<TOTALS_F64>("totals chain f64 (4 instr)", UNROLL, dout, "chain");
+    run<TOTALS_INT>("totals chain int (4 instr)", UNROLL, dout, "chain");
     run<MFMA16_XOR_SAME>("mfma16x16x4 + 4 xor (same wave)", UNROLL, dout, "group");
     run<MFMA16_MAD64_SAME>("mfma16x16x4 + 2 mad64 (same wave)", UNROLL, dout, "group");
     return 0;
