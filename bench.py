@@ -416,10 +416,11 @@ def main():
                                   "survey_frac_whole_step": (launch_samples * shape.n_harmonics / (elapsed / args.steps))
                                                             * SURVEY_FLOPS_PER_HS / 1e12 / FP32_VECTOR_PEAK_TFLOPS},
                          "noise_frame": {"bound": "hbm", "kernel": "noise_frame", "achieved": noise_achieved, "peak": HBM_PEAK_GBS,
-                                         "unit": "GB/s", "frac": noise_achieved / HBM_PEAK_GBS, "traffic": traffic_of("noise_batched_kernel"),
+                                         "unit": "GB/s", "frac": noise_achieved / HBM_PEAK_GBS, "traffic": traffic_of("noise_wave_kernel"),
                                          "algorithmic_bytes_per_launch": launch_samples * noise_bps,
                                          "algorithmic_bytes_per_sample": noise_bps, "avg_launch_ms": noise_ms,
-                                         "note": "direct form at hop 128: (hop/2 + F) multiply-adds per sample -> VALU-bound too",
+                                         "note": "wavefront-private form at hop 128 (round 3): truncated convolution hop/2 multiply-adds per sample on the vector "
+                                                 "pipe + F per sample as fp32 matrix-core products + 10 Philox rounds per 4 samples -> VALU-bound",
                                          "valu": {"mac_per_sample": noise_macs,
                                                   "achieved_Tlaneops": launch_samples * noise_macs / (noise_ms * 1e-3) / 1e12,
                                                   "peak_Tlaneops": VALU_PEAK_TLANEOPS,

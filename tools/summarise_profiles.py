@@ -15,7 +15,7 @@ import sys
 
 src, rnd = sys.argv[1], sys.argv[2]
 dst = src
-KEYS = ("osc_synth_kernel", "osc_totals_kernel", "osc_supscan_kernel", "noise_batched_kernel", "noise_frame_kernel")
+KEYS = ("osc_synth_kernel", "osc_totals_kernel", "osc_supscan_kernel", "noise_wave_kernel", "noise_fft_kernel", "noise_batched_kernel", "noise_frame_kernel")
 
 
 def short(name):
@@ -55,6 +55,8 @@ for k, cs in pmc.items():
         d["hbm_bytes_per_launch"] = d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
     if d.get("GRBM_GUI_ACTIVE") and d.get("SQ_INSTS_VALU"):
         d["cycles_per_valu_inst_per_simd"] = (d["GRBM_GUI_ACTIVE"] / 8.0) / (d["SQ_INSTS_VALU"] / 1024.0)
+    if d.get("SQ_WAVE_CYCLES") and d.get("SQ_WAIT_ANY") is not None:
+        d["wait_any_share_of_wave_cycles"] = d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"]
     out[k] = d
 # stamp: the kernel sources these counters were measured on (bench.py drops `roofline.traffic` when HEAD's sources differ)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
