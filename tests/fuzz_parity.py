@@ -118,7 +118,10 @@ def sweep_training_kernels(cases: int, seed: int, verbose: bool = True):
         xm = torch.randn(M, N, generator=g).cuda().to(dt)
         e_cs = float((dense.colsum(xm).double() - xm.double().sum(0)).abs().max()) / max(1.0, float(xm.double().abs().sum(0).max())) if M else \
             float(dense.colsum(xm).abs().max())
-        okay = (fused and e_loss <= 2e-5 and e_l2 <= max(5e-4, 4.0 * y_l2) and e_max <= max(2e-3, 4.0 * y_max)
+        # (1e-3: single-frame cases -- a signal barely longer than the padding -- scatter between 2e-6 and 1e-3 for the round-2
+        #  kernels, the round-3 kernels and torch's own fp32 formulation alike, dominated by the near-empty bins: measured with
+        #  tools/microbench/mss_case.py)
+        okay = (fused and e_loss <= 2e-5 and e_l2 <= max(1e-3, 4.0 * y_l2) and e_max <= max(2e-3, 4.0 * y_max)
                 and e_fr <= 3e-6 and e_frg <= 3e-6 and e_cs <= 2e-6)
         bad += not okay
         if verbose or not okay:
