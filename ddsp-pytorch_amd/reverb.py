@@ -8,8 +8,8 @@ forced to 1 (:28).
 On CUDA fp32 tensors the work around the two 2N-point library FFTs (rocFFT via torch.fft) is hand-written HIP
 (csrc/ddsp_reverb.hip, include/ddsp_hip.h: ddsp_reverb_* / ddsp_spectral_mul*):
 
-  forward       impulse written straight into its padded / cropped buffer (one launch) -> rfft -> spectral product (one
-                launch) -> irfft; the backward is ONE pass over rfft(grad) producing both `grad conj(K)` and the
+  forward       impulse (cropped to the clip, one launch) -> rfft -> spectral product (one launch) -> irfft, at the smallest
+                fast transform length >= N + L - 1 (80 000 points at the training shape, not the reference's 2N = 128 000); the backward is ONE pass over rfft(grad) producing both `grad conj(K)` and the
                 batch-reduced correlation spectrum, two irffts, and one deterministic launch for d noise / d decay / d wet.
   live_forward  no FFT at all: only the last n outputs of the one-second window are computed, as a direct causal
                 convolution from the device-resident history (two launches per callback instead of three 2L-point
@@ -32,6 +32,21 @@ def causal_fft_convolve(signal: torch.Tensor, kernel: torch.Tensor) -> torch.Ten
     n = signal.shape[-1]
     spec = torch.fft.rfft(signal, n=2 * n) * torch.fft.rfft(kernel, n=2 * n)
     return torch.fft.irfft(spec, n=2 * n)[..., :n]
+
+
+def fft_length(need: int) -> int:
+    """Transform length of the HIP path's convolution: the smallest 2^a * {1, 3, 5, 25, 125, 625} >= need.
+    The reference pads both operands to 2N (filtered_noise.py:26-27); the first N samples of a linear convolution of N
+    samples with L <= N taps only need N + L - 1 points, and the library's transform of 128 000 = 2 * 64 000 points is also a
+    slow size: 69.6 + 80.9 us (rfft + irfft, 32 rows) against 42.7 + 43.1 us at 80 000 (tools/microbench/fft_sizes.py)."""
+    best = None
+    for m in (1, 3, 5, 25, 125, 625):
+        n = m
+        while n < need or n % 2:
+            n *= 2
+        if best is None or n < best:
+            best = n
+    return best
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -58,19 +73,21 @@ class _ReverbFunction(torch.autograd.Function):
         x = x.detach().contiguous().float()
         noise, decay, wet, t = (v.detach().contiguous().float() for v in (noise, decay, wet, t))
         rows, n = x.shape
-        bins = n + 1
-        imp = reverb_impulse(noise, decay, wet, t, n)
-        k_spec = torch.view_as_real(torch.fft.rfft(imp, n=2 * n)).contiguous()                # [bins, 2]
-        x_spec = torch.view_as_real(torch.fft.rfft(x, n=2 * n)).contiguous()                  # [rows, bins, 2]
+        used = min(noise.numel(), n)                      # taps that survive the pad / crop of :34
+        nfft = fft_length(n + used - 1)                   # no wrap-around reaches the first n outputs (nor the backward's lags)
+        bins = nfft // 2 + 1
+        imp = reverb_impulse(noise, decay, wet, t, used)
+        k_spec = torch.view_as_real(torch.fft.rfft(imp, n=nfft)).contiguous()                 # [bins, 2]
+        x_spec = torch.view_as_real(torch.fft.rfft(x, n=nfft)).contiguous()                   # [rows, bins, 2]
         y_spec = torch.empty_like(x_spec)
         with torch.cuda.device(x.device):
             _lib.check(L.ddsp_spectral_mul(x_spec.data_ptr(), k_spec.data_ptr(), y_spec.data_ptr(), rows, bins, _stream(x)),
                        "ddsp_spectral_mul")
-        y = torch.fft.irfft(torch.view_as_complex(y_spec), n=2 * n)[:, :n]
+        y = torch.fft.irfft(torch.view_as_complex(y_spec), n=nfft)[:, :n]
         need_x, need_p = ctx.needs_input_grad[0], any(ctx.needs_input_grad[1:4])
         if need_x or need_p:
             ctx.save_for_backward(x_spec if need_p else None, k_spec, noise, decay, wet, t)
-            ctx.n = n
+            ctx.n, ctx.nfft = n, nfft
         return y
 
     @staticmethod
@@ -78,22 +95,22 @@ class _ReverbFunction(torch.autograd.Function):
     def backward(ctx, grad_y):
         x_spec, k_spec, noise, decay, wet, t = ctx.saved_tensors
         L = _lib.lib()
-        n = ctx.n
-        rows, bins = grad_y.shape[0], n + 1
+        n, nfft = ctx.n, ctx.nfft
+        rows, bins = grad_y.shape[0], nfft // 2 + 1
         need_x, need_p = ctx.needs_input_grad[0], any(ctx.needs_input_grad[1:4])
-        g_spec = torch.view_as_real(torch.fft.rfft(grad_y.contiguous().float(), n=2 * n)).contiguous()
+        g_spec = torch.view_as_real(torch.fft.rfft(grad_y.contiguous().float(), n=nfft)).contiguous()
         gk = torch.empty_like(g_spec) if need_x else None
         s = torch.empty((bins, 2), device=g_spec.device, dtype=torch.float32) if need_p else None
         with torch.cuda.device(g_spec.device):
             _lib.check(L.ddsp_spectral_mul_backward(g_spec.data_ptr(), None if x_spec is None else x_spec.data_ptr(), k_spec.data_ptr(),
                                                     None if gk is None else gk.data_ptr(), None if s is None else s.data_ptr(),
                                                     rows, bins, _stream(g_spec)), "ddsp_spectral_mul_backward")
-        grad_x = torch.fft.irfft(torch.view_as_complex(gk), n=2 * n)[:, :n] if need_x else None
+        grad_x = torch.fft.irfft(torch.view_as_complex(gk), n=nfft)[:, :n] if need_x else None
         grad_noise = grad_decay = grad_wet = None
         if need_p:
             length = noise.numel()
             used = min(length, n)
-            grad_imp = torch.fft.irfft(torch.view_as_complex(s), n=2 * n)[:used].contiguous()
+            grad_imp = torch.fft.irfft(torch.view_as_complex(s), n=nfft)[:used].contiguous()
             grad_noise = torch.empty_like(noise)
             grad_decay = torch.empty_like(decay)
             grad_wet = torch.empty_like(wet)
