@@ -206,6 +206,8 @@ int ddsp_stft_frames_backward(const float *grad_frames, const float *window, flo
  *   grad_frames nullable; [B * (1 + L / hop), n_fft] = d loss / d (windowed frame of x_pred), to be folded back onto the
  *               waveform with ddsp_stft_frames_backward (which applies the window)
  *   scratch     ddsp_mss_scale_scratch_bytes() bytes
+ * eps must be a normal positive float (>= 1.1754944e-38; the kernels take the hardware log2 / reciprocal of P + eps), else
+ * DDSP_EINVAL.  The window is read as [n_fft] floats (8-byte aligned for n_fft = 2048).
  */
 size_t ddsp_mss_scale_scratch_bytes(void);
 int ddsp_mss_scale_supported(int n_fft);
