@@ -42,6 +42,15 @@ struct MssParams {
     float alpha, eps, inv_n;
 };
 
+// DDSP_MSS_IEEE (experiments): library log2 and IEEE division instead of v_log_f32 / v_rcp_f32
+#ifdef DDSP_MSS_IEEE
+__device__ __forceinline__ float fast_log2(float x) { return log2f(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
+#else
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+
 __device__ __forceinline__ float sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 
 __device__ __forceinline__ int reflect_index(int i, int L)
@@ -224,13 +233,13 @@ __global__ void __launch_bounds__(64) mss_wave_kernel(MssParams p, long nunits)
             const float da = Pa - Qa, db = Pb - Qb;
             // (P + eps >= eps > 0 is a normal number: the hardware log2 and reciprocal need no denormal handling; v_rcp_f32 is within
             //  1 ulp, far inside the gradient's tolerance)
-            const float ea = __builtin_amdgcn_logf(Qa + p.eps) - __builtin_amdgcn_logf(Pa + p.eps);
-            const float eb = __builtin_amdgcn_logf(Qb + p.eps) - __builtin_amdgcn_logf(Pb + p.eps);
+            const float ea = fast_log2(Qa + p.eps) - fast_log2(Pa + p.eps);
+            const float eb = fast_log2(Qb + p.eps) - fast_log2(Pb + p.eps);
             lin += fabsf(da) + fabsf(db);                         // a frame past the end is all zero: P = Q = 0, both terms vanish
             lg += fabsf(ea) + fabsf(eb);
             if (p.grad_frames) {
-                const float ca = 2.0f * p.inv_n * (sgn(da) - p.alpha * sgn(ea) * inv_ln2 * __builtin_amdgcn_rcpf(Pa + p.eps));
-                const float cb = 2.0f * p.inv_n * (sgn(db) - p.alpha * sgn(eb) * inv_ln2 * __builtin_amdgcn_rcpf(Pb + p.eps));
+                const float ca = 2.0f * p.inv_n * (sgn(da) - p.alpha * sgn(ea) * inv_ln2 * fast_rcp(Pa + p.eps));
+                const float cb = 2.0f * p.inv_n * (sgn(db) - p.alpha * sgn(eb) * inv_ln2 * fast_rcp(Pb + p.eps));
                 const cf GA = make_float2(ca * A.x, ca * A.y), GB = make_float2(cb * Bq.x, cb * Bq.y);
                 if (k == 0 || k == N / 2) {
                     zrow[k] = make_float2(GA.x, GB.x);
@@ -338,11 +347,17 @@ __global__ void __launch_bounds__(64) mss_wave2048_kernel(MssParams p, long nuni
         ddsp_wfft::store_natural<R1>(v, bufW, lane);
         DDSP_WAVE_ORDER();
 
-        cf wk = wbase;                                    // W_2048^k, k = lane + 64 it: advanced by W_32 per trip
-        constexpr float c32 = 0.98078528040323043f, s32 = 0.19509032201612825f;       // cos, sin of 2 pi / 32
+        // W_2048^k, k = lane + 64 it, = W_2048^lane * W_32^it: one product with an exact-to-the-ulp constant per trip (advancing a
+        // running twiddle by W_32 eight times costs 5e-7 of relative accuracy, which near-empty bins amplify a thousandfold)
+        constexpr float c32[9] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
+                                  0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f, 0.0f};
+        constexpr float s32[9] = {0.0f, 0.19509032201612825f, 0.38268343236508977f, 0.55557023301960218f, 0.70710678118654752f,
+                                  0.83146961230254524f, 0.92387953251128674f, 0.98078528040323043f, 1.0f};
 #pragma unroll 1
         for (int it = 0; it < 9; ++it) {
             const int k = lane + 64 * it;
+            // (wx + i wy)(c - i s)
+            const cf wk = make_float2(__fmaf_rn(wbase.x, c32[it], wbase.y * s32[it]), __fmaf_rn(wbase.y, c32[it], -(wbase.x * s32[it])));
             if (k <= M / 2) {
                 const int km = (M - k) & (M - 1);
                 const cf zk = bufZ[k], zm = bufZ[km], qk = bufW[k], qm = bufW[km];
@@ -356,14 +371,14 @@ __global__ void __launch_bounds__(64) mss_wave2048_kernel(MssParams p, long nuni
                 const float P1 = __fmaf_rn(X1.x, X1.x, X1.y * X1.y), P2 = __fmaf_rn(X2.x, X2.x, X2.y * X2.y);
                 const float R1q = __fmaf_rn(Q1.x, Q1.x, Q1.y * Q1.y), R2q = __fmaf_rn(Q2.x, Q2.x, Q2.y * Q2.y);
                 const float d1 = P1 - R1q, d2 = P2 - R2q;
-                const float e1 = __builtin_amdgcn_logf(R1q + p.eps) - __builtin_amdgcn_logf(P1 + p.eps);
-                const float e2 = __builtin_amdgcn_logf(R2q + p.eps) - __builtin_amdgcn_logf(P2 + p.eps);
+                const float e1 = fast_log2(R1q + p.eps) - fast_log2(P1 + p.eps);
+                const float e2 = fast_log2(R2q + p.eps) - fast_log2(P2 + p.eps);
                 lin += fabsf(d1) + (twice ? fabsf(d2) : 0.0f);
                 lg += fabsf(e1) + (twice ? fabsf(e2) : 0.0f);
                 if (p.grad_frames) {
                     const float h = (k == 0) ? 1.0f : 0.5f;       // bins 0 and M are real and not halved
-                    const float c1 = h * 2.0f * p.inv_n * (sgn(d1) - p.alpha * sgn(e1) * inv_ln2 * __builtin_amdgcn_rcpf(P1 + p.eps));
-                    const float c2 = h * 2.0f * p.inv_n * (sgn(d2) - p.alpha * sgn(e2) * inv_ln2 * __builtin_amdgcn_rcpf(P2 + p.eps));
+                    const float c1 = h * 2.0f * p.inv_n * (sgn(d1) - p.alpha * sgn(e1) * inv_ln2 * fast_rcp(P1 + p.eps));
+                    const float c2 = h * 2.0f * p.inv_n * (sgn(d2) - p.alpha * sgn(e2) * inv_ln2 * fast_rcp(P2 + p.eps));
                     const cf G1 = make_float2(c1 * X1.x, c1 * X1.y), G2 = make_float2(c2 * X2.x, c2 * X2.y);         // G'[k], G'[M - k]
                     const cf S = make_float2(G1.x + G2.x, G1.y - G2.y), D = make_float2(G1.x - G2.x, G1.y + G2.y);
                     // i conj(w) D = i (wx + i*(-wy))... with w = (wx, wy): conj(w) D = (wx Dx + wy Dy, wx Dy - wy Dx)
@@ -376,7 +391,6 @@ __global__ void __launch_bounds__(64) mss_wave2048_kernel(MssParams p, long nuni
                     }
                 }
             }
-            wk = make_float2(__fmaf_rn(wk.x, c32, wk.y * s32), __fmaf_rn(wk.y, c32, -(wk.x * s32)));                // times W_32 = (c, -s)
         }
         DDSP_WAVE_ORDER();
         if (p.grad_frames) {
