@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) noise_frame_kernel(NoiseParams p)
             philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (4 * q + e < R) x[4 * q + e] = (float)(r[e] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+                if (4 * q + e < R) x[4 * q + e] = philox_to_sample(r[e]);
         }
     }
     __syncthreads();
@@ -243,10 +243,10 @@ __global__ void __launch_bounds__(kNT) noise_batched_kernel(NoiseParams p)
             uint32_t r[4];
             philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r);
             float4 v;
-            v.x = (float)(r[0] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
-            v.y = (float)(r[1] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
-            v.z = (float)(r[2] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
-            v.w = (float)(r[3] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+            v.x = philox_to_sample(r[0]);
+            v.y = philox_to_sample(r[1]);
+            v.z = philox_to_sample(r[2]);
+            v.w = philox_to_sample(r[3]);
             *reinterpret_cast<float4 *>(&xs[f * XS + 8 + 4 * q]) = v;
         }
     }
@@ -325,7 +325,7 @@ __device__ __forceinline__ float noise_sample(const float *u, long frame, int m,
     const uint64_t ctr = offset + (uint64_t)frame * (uint64_t)quads + (uint64_t)(m >> 2);
     uint32_t r[4];
     philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    return (float)(r[m & 3] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+    return philox_to_sample(r[m & 3]);
 }
 
 // Generic backward: one frame per workgroup, any hop / F.
@@ -407,10 +407,10 @@ __global__ void __launch_bounds__(kNT) noise_bwd_batched_kernel(NoiseBwdParams p
             uint32_t r[4];
             philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32), r);
             float4 v;
-            v.x = (float)(r[0] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
-            v.y = (float)(r[1] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
-            v.z = (float)(r[2] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
-            v.w = (float)(r[3] >> 8) * (1.0f / 16777216.0f) * 2.0f - 1.0f;
+            v.x = philox_to_sample(r[0]);
+            v.y = philox_to_sample(r[1]);
+            v.z = philox_to_sample(r[2]);
+            v.w = philox_to_sample(r[3]);
             *reinterpret_cast<float4 *>(&xs[f * XS + 4 * q]) = v;
         }
     }

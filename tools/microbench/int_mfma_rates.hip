@@ -26,7 +26,12 @@ __device__ __forceinline__ void philox(unsigned c0, unsigned c1, unsigned k0, un
     for (int r = 0; r < 10; ++r) {
         const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
         const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+#ifdef PHILOX_XOR2
         const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+#else
+        const unsigned n0 = __builtin_amdgcn_bitop3_b32((unsigned)(p1 >> 32), c[1], k0, 0x96), n1 = (unsigned)p1;
+        const unsigned n2 = __builtin_amdgcn_bitop3_b32((unsigned)(p0 >> 32), c[3], k1, 0x96), n3 = (unsigned)p0;
+#endif
         c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
