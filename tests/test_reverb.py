@@ -164,3 +164,18 @@ def test_reverb_reference_fixtures_round2_cpu():
 @pytest.mark.gpu
 def test_reverb_reference_fixtures_round2_gpu():
     _check_g16("cuda", 5e-6, 5e-5)
+
+
+def test_transform_length_of_the_hip_path():
+    """reverb.fft_length: the smallest 2^a * {1, 3, 5, 25, 125, 625} >= need, always even (rfft / irfft pair), and never
+    shorter than the linear convolution needs (N + L - 1: no wrap-around into the first N outputs)."""
+    from ddsp_pytorch_amd.reverb import fft_length
+    assert fft_length(64000 + 16000 - 1) == 80000          # the training shape: 80 000 points, not the reference's 2N = 128 000
+    for need in (1, 2, 3, 5, 7, 1023, 1024, 1025, 5119, 79999, 88199, 239999, 1 << 20):
+        n = fft_length(need)
+        assert n >= need and n % 2 == 0
+        m = n
+        while m % 2 == 0:
+            m //= 2
+        assert m in (1, 3, 5, 25, 125, 625)
+        assert n < 2 * max(need, 2) + 2                    # never worse than the next power of two
