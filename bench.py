@@ -420,7 +420,7 @@ def main():
                                          "algorithmic_bytes_per_launch": launch_samples * noise_bps,
                                          "algorithmic_bytes_per_sample": noise_bps, "avg_launch_ms": noise_ms,
                                          "note": "wavefront-private form at hop 128 (round 3): truncated convolution hop/2 multiply-adds per sample on the vector "
-                                                 "pipe + F per sample as fp32 matrix-core products + 10 Philox rounds per 4 samples -> VALU-bound",
+                                                 "pipe + F per sample as split-bf16 matrix-core products + 10 Philox rounds per 4 samples -> VALU-bound",
                                          "valu": {"mac_per_sample": noise_macs,
                                                   "achieved_Tlaneops": launch_samples * noise_macs / (noise_ms * 1e-3) / 1e12,
                                                   "peak_Tlaneops": VALU_PEAK_TLANEOPS,

@@ -11,10 +11,15 @@
 //   * impulse responses (:8-20): z = irfft(H) is a product with ONE cosine matrix shared by every frame,
 //         E'[f][n] = sum_{k even} w_k H[f][k] cos(2 pi k n / 128)   (w = 1/2 for k in {0, 64}),   O[f][n] = sum_{k odd} H[f][k] cos(2 pi k n / 128),
 //         z[n] = (E' + O) / 64,  z[64 - n] = (E' - O) / 64,  n = 0..31   (cos(2 pi k (64 - n) / 128) = (-1)^k cos(2 pi k n / 128)),
-//     i.e. a [16 frames x 33] x [33 x 32] and a [16 x 32] x [32 x 32] fp32 product: v_mfma_f32_16x16x4_f32 with the cosine
-//     operand resident in registers for the whole kernel (exact fp32 fused multiply-adds in k order; the matrix cores are used
-//     because this step IS a dense contraction with a shared operand -- one instruction per 1024 multiply-adds and no table reads;
-//     measured: they do NOT run beside the vector pipe for fp32, tools/microbench/int_mfma_rates.hip).  The result layout puts a
+//     i.e. a [16 frames x 32] x [32 x 32] product for each parity (bin 64 is a rank-one term added by the tap stage).  The
+//     contraction has a shared operand, so it runs on the matrix cores -- as SPLIT bf16: every fp32 value is hi + mid + lo, three
+//     bf16 terms that represent it exactly (8 + 8 + 8 significand bits), and a product is the six cross terms of weight >= 2^-16
+//     (hi hi, hi mid, mid hi, hi lo, mid mid, lo hi) of v_mfma_f32_16x16x32_bf16, fp32 accumulate: 24 instructions per group and
+//     the dropped terms are below 2^-26 |a||b|, a quarter of an fp32 rounding.  (The fp32 matrix instruction,
+//     v_mfma_f32_16x16x4_f32 x 34, was exact in k order but does NOT run beside the vector pipe -- measured,
+//     tools/microbench/int_mfma_rates.hip -- and cost 1088 cycles per group; the split form holds the issue port a quarter of
+//     that and its splitting arithmetic is ~90 vector instructions.  Measured same box: 0.1035 -> 0.0994 ms.)  The cosine
+//     operand's split is resident in registers for the whole kernel.  The result layout puts a
 //     fixed tap index n on every lane: the PRODUCING lane windows z (periodic Hann, :15) and stores it at both of its wrapped
 //     positions (:14,:19-20) -- no scatter pass, no table.  n = 32 is one signed sum.
 //   * noise (:44-48): the injected draw or Philox4x32-10, counter layout of ddsp_noise_common.h (streams identical to every other form).
@@ -45,7 +50,18 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 struct Tile { v4f v[5]; };           // a group's 16 x 65 filter magnitudes, 260 x 16 bytes over 64 lanes
 struct Lines { v4f v[8]; };          // a group's 16 x 128 outputs, 512 x 16 bytes over 64 lanes
 struct Pass { float v[16]; };        // a lane's two output chunks of one convolution pass
-struct Spectra { v4f e[2], o[2]; float z32; };
+struct Spectra { v4f e[2], o[2], h64; float z32; };
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Split { bf16x8 p[3]; };       // eight fp32 values as three bf16 terms each, hi + mid + lo == the value exactly
+// x = hi + mid + lo with every term a bf16: both residuals are exact in fp32 (8 + 8 + 8 significand bits)
+__device__ __forceinline__ void split3(float x, Split &d, int j)
+{
+    const __bf16 hi = (__bf16)x;
+    const float r1 = x - (float)hi;
+    const __bf16 mid = (__bf16)r1;
+    const float r2 = r1 - (float)mid;
+    d.p[0][j] = hi; d.p[1][j] = mid; d.p[2][j] = (__bf16)r2;
+}
 
 constexpr int R = 128;            // hop = samples per frame
 constexpr int F = 65;             // bands; S = 2 (F - 1) = 128 = R: the impulse response fills the frame exactly
@@ -72,10 +88,6 @@ constexpr int kLdsFloats = FG * KS + FG * XS;
 
 #define DDSP_WAVE_ORDER() do { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 
-// even-bin / odd-bin index a lane (quarter q = lane >> 4) feeds into K-step s of the products; chosen so that the two
-// quarters that share a ds_read_b32 service group read bins 16 apart (row stride 65: different banks for all 32 lanes)
-__device__ __forceinline__ int bin_index(int s, int q) { return 16 * (s >> 2) + 2 * (s & 3) + (q >> 1) + 8 * (q & 1); }
-
 template <bool ACC>   // ACC: add to the output buffer's contents (harmonics + noise, decoder.py:132) instead of overwriting them
 __global__ void __launch_bounds__(64, 2) noise_wave_kernel(NoiseParams p, long ngroups)
 {
@@ -91,7 +103,7 @@ __global__ void __launch_bounds__(64, 2) noise_wave_kernel(NoiseParams p, long n
 #endif
 
     // ---- per-lane constants, resident for the whole kernel -------------------------------------------------------------
-    // matrix-core operand lanes: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], D[4 (lane >> 4) + r][lane & 15]
+    // matrix-core operand lanes: A[i = lane & 15][k = 8 (lane >> 4) + j], B[k = 8 (lane >> 4) + j][n = lane & 15], D[4 (lane >> 4) + r][lane & 15]
     const int mi0 = lane & 15, mq0 = lane >> 4;
     // the 128 distinct values cos(2 pi m / 128), two per lane, through LDS once (38 library cosines per lane cost a tenth of the
     // kernel's time at eight groups per wavefront)
@@ -99,20 +111,16 @@ __global__ void __launch_bounds__(64, 2) noise_wave_kernel(NoiseParams p, long n
     ctab[lane] = cospif((float)lane * (1.0f / 64.0f));
     ctab[lane + 64] = cospif((float)(lane + 64) * (1.0f / 64.0f));
     DDSP_WAVE_ORDER();
-    float Be[2][9], Bo[2][8];                 // cosine operand, tile t: n = 16 t + mi
+    // cosine operand of v_mfma_f32_16x16x32_bf16, tile t (n = 16 t + mi): B[k = 8 mq + j][n], k = the even bin 2k / the odd bin 2k + 1
+    Split Be[2], Bo[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int n = 16 * t + mi0;
 #pragma unroll
-        for (int s = 0; s < 9; ++s) {
-            const int e = (s < 8) ? bin_index(s, mq0) : (mq0 == 0 ? 32 : -1);
-            const float w = (e < 0) ? 0.0f : ((e == 0 || e == 32) ? 0.5f : 1.0f);
-            Be[t][s] = w * ctab[(2 * (e < 0 ? 0 : e) * n) & 127];
-        }
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int o = bin_index(s, mq0);
-            Bo[t][s] = ctab[((2 * o + 1) * n) & 127];
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * mq0 + j;
+            split3((k == 0 ? 0.5f : 1.0f) * ctab[(2 * k * n) & 127], Be[t], j);
+            split3(ctab[((2 * k + 1) * n) & 127], Bo[t], j);
         }
     }
     // window weights of the taps this lane produces: z[n] * win(n), z[64 - n] * win(64 - n), win(m) = 0.5 + 0.5 cos(2 pi m / 128),
@@ -142,45 +150,45 @@ __global__ void __launch_bounds__(64, 2) noise_wave_kernel(NoiseParams p, long n
     //  the loop they would all stay live across it, some forty registers, and push the convolution's operands into scratch)
     auto opaque_lane = [&]() { int ln = lane; asm volatile("" : "+v"(ln)); return ln; };
 
-    // H tile (registers) -> LDS, operand reads, the 34 products.  Results stay in accE / accO.
+    // H tile (registers) -> LDS, operand reads and splits, the 24 products.  Results stay in accE / accO.
     auto products = [&](const Tile h) {
         const int ln = opaque_lane(), mi = ln & 15, mq = ln >> 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<v4f *>(Hs + 4 * (ln + 64 * j)) = h.v[j];
         if (ln < 4) *reinterpret_cast<v4f *>(Hs + 4 * (ln + 256)) = h.v[4];
         DDSP_WAVE_ORDER();
-        float Ae[9], Ao[8];
-        const float *hrow = Hs + mi * F;
+        // lane (frame mi, quarter mq) reads H[mi][16 mq .. 16 mq + 16): even positions are its 8 even bins, odd its 8 odd bins
+        // (row stride 65: the 32 lanes of a service group hit 32 different banks)
+        const float *hrow = Hs + mi * F + 16 * mq;
+        float hv[16];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int b = bin_index(s, mq);
-            Ae[s] = hrow[2 * b];
-            Ao[s] = hrow[2 * b + 1];
-        }
-        Ae[8] = (mq == 0) ? hrow[64] : 0.0f;
-        DDSP_WAVE_ORDER();
+        for (int j = 0; j < 16; ++j) hv[j] = hrow[j];
+        const float h64 = Hs[mi * F + 64];
         Spectra sp;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sp.h64[r] = 0.5f * Hs[(4 * mq + r) * F + 64];
+        DDSP_WAVE_ORDER();
+        Split Ae, Ao;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { split3(hv[2 * j], Ae, j); split3(hv[2 * j + 1], Ao, j); }
         v4f (&accE)[2] = sp.e, (&accO)[2] = sp.o;
         accE[0] = accE[1] = accO[0] = accO[1] = (v4f){0, 0, 0, 0};
+        // six of the nine cross terms, smallest first: the three dropped ones are below 2^-26 of |a||b|
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-        for (int s = 0; s < (DDSP_NOISE_ABL == 3 ? 1 : 9); ++s) {
-            accE[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ae[s], Be[0][s], accE[0], 0, 0, 0);
-            accE[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ae[s], Be[1][s], accE[1], 0, 0, 0);
-            if (s < 8) {
-                accO[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ao[s], Bo[0][s], accO[0], 0, 0, 0);
-                accO[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ao[s], Bo[1][s], accO[1], 0, 0, 0);
-            }
+        for (int i = 0; i < (DDSP_NOISE_ABL == 3 ? 1 : 6); ++i) {
+            accE[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ae.p[PA[i]], Be[0].p[PB[i]], accE[0], 0, 0, 0);
+            accE[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ae.p[PA[i]], Be[1].p[PB[i]], accE[1], 0, 0, 0);
+            accO[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ao.p[PA[i]], Bo[0].p[PB[i]], accO[0], 0, 0, 0);
+            accO[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ao.p[PA[i]], Bo[1].p[PB[i]], accO[1], 0, 0, 0);
         }
-        // n = 32: cos(2 pi k 32 / 128) = cos(pi k / 2): (-1)^(k/2) for even k, 0 for odd k; the sign of this lane's even bins is
-        // that of its quarter ((mq >> 1) odd <=> bin_index odd)
-        float t = (mq != 0) ? Ae[0] : 0.5f * Ae[0];
+        // n = 32: cos(pi k / 2) = (-1)^(k/2) for even k, 0 for odd k; even bin 2 (8 mq + j) has the sign (-1)^j
+        float t = (mq == 0 ? 0.5f : 1.0f) * hv[0];
 #pragma unroll
-        for (int s = 1; s < 8; ++s) t += Ae[s];
-        t += 0.5f * Ae[8];
-        if (mq & 2) t = -t;
+        for (int j = 1; j < 8; ++j) t += (j & 1) ? -hv[2 * j] : hv[2 * j];
         t += __shfl_xor(t, 16);
         t += __shfl_xor(t, 32);
-        sp.z32 = t * (0.5f / 64.0f);                               // win(32) = 0.5
+        sp.z32 = (t + 0.5f * h64) * (0.5f / 64.0f);                 // bin 64: (-1)^32; win(32) = 0.5
         return sp;
     };
 
@@ -195,8 +203,9 @@ __global__ void __launch_bounds__(64, 2) noise_wave_kernel(NoiseParams p, long n
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float *kr = kern + (4 * mq + r) * KS;
-                const float v1 = (accE[t][r] + accO[t][r]) * w1[t];
-                const float v2 = (accE[t][r] - accO[t][r]) * w2[t];
+                const float ev = accE[t][r] + ((mi & 1) ? -sp.h64[r] : sp.h64[r]);      // bin 64: cos(pi n) / 2
+                const float v1 = (ev + accO[t][r]) * w1[t];
+                const float v2 = (ev - accO[t][r]) * w2[t];
                 kr[n] = v1;
                 if (n != 0) { kr[128 - n] = v1; kr[64 - n] = v2; }
                 kr[64 + n] = v2;                                  // n = 0: win(64) = 0, the reference's hann[0]
