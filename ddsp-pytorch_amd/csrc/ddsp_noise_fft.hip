@@ -40,6 +40,26 @@ namespace {
 
 using namespace ddsp_wfft;
 
+// Power-of-two equaliser of a frame.  Two frames share every transform of this file (one in the real part, one in the imaginary part), so
+// each carries an fp32-epsilon share of the other: harmless when they are equally loud, a relative error of eps * ratio in the quiet
+// one when they are not (the reference transforms every frame alone).  Everything here is linear in the frame's magnitudes / gradient
+// row, so the frame is scaled by 2^-e on the way in and by 2^e on the way out -- exact -- with e the exponent of its largest
+// magnitude: both halves of a pair then sit in [0.5, 1).  An all-zero frame comes out as exact zeros (as the reference's does),
+// not as its partner's rounding residue.  `m`: the lane's own max |value|; `c_in`, `c_out`: the constants the two scalings fold into.
+struct FrameScale { float in, out; };
+__device__ __forceinline__ FrameScale frame_scale(float m, float c_in, float c_out)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+    int e = 0;
+    if (m > 0.0f && m < __builtin_huge_valf()) (void)frexpf(m, &e);
+    e = max(-100, min(100, e));                         // 2^-e and 2^e stay normal numbers whatever the input holds
+    FrameScale s;
+    s.in = ldexpf(c_in, -e);
+    s.out = (m == 0.0f) ? 0.0f : ldexpf(c_out, e);
+    return s;
+}
+
 struct FrameSrc {
     long frame;   // index into [B*T]
     bool valid;
@@ -129,9 +149,16 @@ __global__ void __launch_bounds__(64, 2) noise_fft_kernel(NoiseParams p, long np
 
         // ---- 1. impulse responses -> kk[j] = k_a[j] + i k_b[j] in bufB[0, R) ----------------------------------
         cf h[8];
+        FrameScale sca, scb;                                      // the pair's equalisers; .out carries the 1/(4N) of split + inverse transform
+        constexpr float kOut = 1.0f / (4.0f * (float)N);
         if (IRFFT) {
+            float ma = 0.0f, mb = 0.0f;
 #pragma unroll
-            for (int n1 = 0; n1 < 8; ++n1) h[n1] = make_float2(hcur.a[n1], hcur.b[n1]);
+            for (int n1 = 0; n1 < 8; ++n1) { ma = fmaxf(ma, fabsf(hcur.a[n1])); mb = fmaxf(mb, fabsf(hcur.b[n1])); }
+            sca = frame_scale(ma, 1.0f, kOut);
+            scb = frame_scale(mb, 1.0f, kOut);
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) h[n1] = make_float2(hcur.a[n1] * sca.in, hcur.b[n1] * scb.in);
         }
         if (IRFFT) {
             fft_wave<8, true, false>(h, tw8, bufB, lane);
@@ -157,7 +184,13 @@ __global__ void __launch_bounds__(64, 2) noise_fft_kernel(NoiseParams p, long np
             const float vb = fr[1].valid ? 1.0f : 0.0f;
             for (int j = lane; j < R; j += 64) bufB[j] = make_float2(0.0f, 0.0f);
             DDSP_WAVE_ORDER();
-            const float invS = 1.0f / (float)S;
+            {
+                float ma = 0.0f, mb = 0.0f;
+                for (int k = lane; k < F; k += 64) { ma = fmaxf(ma, fabsf(Ha[k])); mb = fmaxf(mb, fabsf(Hb[k])); }
+                sca = frame_scale(ma, 1.0f / (float)S, kOut);
+                scb = frame_scale(mb, 1.0f / (float)S, kOut);
+            }
+            const float invSa = sca.in, invSb = scb.in;
             auto emit = [&](int nn, float za, float zb) {
 #pragma unroll
                 for (int wrap = 0; wrap < 2; ++wrap) {
@@ -183,8 +216,8 @@ __global__ void __launch_bounds__(64, 2) noise_fft_kernel(NoiseParams p, long np
                 }
                 if (lane == 0) {
                     const float sg = (half & 1) ? -1.0f : 1.0f;
-                    emit(0, __fmaf_rn(2.0f, ea + oa, h0a + hna) * invS, __fmaf_rn(2.0f, eb + ob, h0b + hnb) * invS);
-                    emit(half, __fmaf_rn(2.0f, ea - oa, h0a + sg * hna) * invS, __fmaf_rn(2.0f, eb - ob, h0b + sg * hnb) * invS);
+                    emit(0, __fmaf_rn(2.0f, ea + oa, h0a + hna) * invSa, __fmaf_rn(2.0f, eb + ob, h0b + hnb) * invSb);
+                    emit(half, __fmaf_rn(2.0f, ea - oa, h0a + sg * hna) * invSa, __fmaf_rn(2.0f, eb - ob, h0b + sg * hnb) * invSb);
                 }
             }
             // n = 1 .. S/4 paired with S/2 - n: cos(2 pi k (S/2 - n) / S) = (-1)^k cos(2 pi k n / S).  Bins two at a time
@@ -223,8 +256,8 @@ __global__ void __launch_bounds__(64, 2) noise_fft_kernel(NoiseParams p, long np
                 if (mine) {
                     const int n2 = half - n;
                     const float sg1 = (n & 1) ? -1.0f : 1.0f, sg2 = (n2 & 1) ? -1.0f : 1.0f;
-                    emit(n, __fmaf_rn(2.0f, ea + oa, h0a + sg1 * hna) * invS, __fmaf_rn(2.0f, eb + ob, h0b + sg1 * hnb) * invS);
-                    if (n2 != n) emit(n2, __fmaf_rn(2.0f, ea - oa, h0a + sg2 * hna) * invS, __fmaf_rn(2.0f, eb - ob, h0b + sg2 * hnb) * invS);
+                    emit(n, __fmaf_rn(2.0f, ea + oa, h0a + sg1 * hna) * invSa, __fmaf_rn(2.0f, eb + ob, h0b + sg1 * hnb) * invSb);
+                    if (n2 != n) emit(n2, __fmaf_rn(2.0f, ea - oa, h0a + sg2 * hna) * invSa, __fmaf_rn(2.0f, eb - ob, h0b + sg2 * hnb) * invSb);
                 }
             }
         }
@@ -290,14 +323,14 @@ __global__ void __launch_bounds__(64, 2) noise_fft_kernel(NoiseParams p, long np
 
         // ---- 5. first R samples: y_a = Re, y_b = Im; staged through LDS for whole-line stores ----------------------
         float *ya = reinterpret_cast<float *>(bufB), *yb = ya + R;
-        constexpr float kScale = 1.0f / (4.0f * (float)N);
+        const float kScaleA = sca.out, kScaleB = scb.out;
 #pragma unroll
         for (int d = 0; d < R1 / 8; ++d)
 #pragma unroll
             for (int k3 = 0; k3 < 4; ++k3) {                      // n = c + 8 R1 k3 < R  <=>  k3 < 4
                 const int n = lane + 64 * d + 8 * R1 * k3;
-                ya[n] = v[d * 8 + k3].x * kScale;
-                yb[n] = v[d * 8 + k3].y * kScale;
+                ya[n] = v[d * 8 + k3].x * kScaleA;
+                yb[n] = v[d * 8 + k3].y * kScaleB;
             }
         DDSP_WAVE_ORDER();
         // the next pair's magnitudes change registers HERE, before this pair's stores are issued: their loads are a whole pair old
@@ -395,11 +428,19 @@ __global__ void __launch_bounds__(64, 2) noise_fft_bwd_kernel(NoiseFftBwdParams 
         const long fa = 2 * pair, fb = (2 * pair + 1 < nframes) ? 2 * pair + 1 : 2 * pair;   // an odd last frame is paired with itself
         const long next = pair + gridDim.x;
         // ---- 1. xx -> bufA[0, R), gg -> bufB[0, R) --------------------------------------------------------------------
+        // (rows equalised by powers of two, frame_scale: a quiet frame's gradient does not drown in its partner's rounding)
+        float ma = 0.0f, mb = 0.0f;
+#pragma unroll
+        for (int e = 0; e < quads / 64; ++e)
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) { ma = fmaxf(ma, fabsf(gcur.a[e][c4])); mb = fmaxf(mb, fabsf(gcur.b[e][c4])); }
+        const FrameScale sca = frame_scale(ma, 1.0f, 1.0f / 512.0f), scb = frame_scale(mb, 1.0f, 1.0f / 512.0f);   // .out: the dH step's 1/S
+        const float sa = sca.in, sb = scb.in;
 #pragma unroll
         for (int e = 0; e < quads / 64; ++e) {
             const int q = lane + 64 * e;
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) bufB[4 * q + c4] = make_float2(gcur.a[e][c4], gcur.b[e][c4]);
+            for (int c4 = 0; c4 < 4; ++c4) bufB[4 * q + c4] = make_float2(gcur.a[e][c4] * sa, gcur.b[e][c4] * sb);
         }
         const Rows gnext = load_rows(next < npairs ? next : pair);                 // (the last pair re-reads its own rows: no branch)
         if (p.u) {
@@ -469,23 +510,22 @@ __global__ void __launch_bounds__(64, 2) noise_fft_bwd_kernel(NoiseFftBwdParams 
                 for (int k3 = 0; k3 < 4; ++k3) {
                     const int n1 = d + 2 * k3;
                     const float wgt = __fmaf_rn(0.5f, win_c * ck[n1] - win_s * sk[n1], 0.5f) * kScale;
-                    h[n1] = make_float2(v[d * 8 + k3].x * wgt, v[d * 8 + k3].y * wgt);
+                    h[n1] = make_float2(v[d * 8 + k3].x * wgt, v[d * 8 + k3].y * wgt);      // (still equalised: one more shared transform)
                 }
             fft_wave<8, false, false>(h, tw8, bufB, lane);        // h[k3] = Z[lane + 64 k3]
 #pragma unroll
             for (int k3 = 0; k3 < 8; ++k3) bufA[lane + 64 * k3] = h[k3];
             DDSP_WAVE_ORDER();
             float *Ha = p.gH + fa * F, *Hb = p.gH + fb * F;
-            constexpr float invS = 1.0f / 512.0f;
 #pragma unroll
             for (int k3 = 0; k3 < 4; ++k3) {
                 const int k = lane + 64 * k3;
                 const cf zm = bufA[(512 - k) & 511];
-                const float cfac = (k == 0) ? 0.5f * invS : invS;
-                Ha[k] = (h[k3].x + zm.x) * cfac;
-                Hb[k] = (h[k3].y + zm.y) * cfac;
+                const float half0 = (k == 0) ? 0.5f : 1.0f;
+                Ha[k] = (h[k3].x + zm.x) * (half0 * sca.out);     // c_k / S and the row's 2^e
+                Hb[k] = (h[k3].y + zm.y) * (half0 * scb.out);
             }
-            if (lane == 0) { Ha[256] = h[4].x * invS; Hb[256] = h[4].y * invS; }          // c_k / (2 S) (Z[256] + Z[256]) with c_k = 1
+            if (lane == 0) { Ha[256] = h[4].x * sca.out; Hb[256] = h[4].y * scb.out; }   // c_k / (2 S) (Z[256] + Z[256]) with c_k = 1
         }
         DDSP_WAVE_ORDER();
         if (next >= npairs) break;
@@ -510,8 +550,8 @@ hipError_t launch(const NoiseParams &p, hipStream_t s)
         cached[dev & 63] = cus;
     }
     cus = cached[dev & 63];
-    // wavefronts a CU holds of this kernel: registers allow 3 (R1 = 16: <= 168 VGPRs) or 5 (R1 = 8: <= 96) per SIMD, LDS 160 KiB / lds
-    const long by_regs = R1 == 16 ? 12 : 20, by_lds = (160 * 1024) / (long)lds;
+    // wavefronts a CU holds of this kernel: registers allow 2 (R1 = 16: 160-224 VGPRs) or 4 (R1 = 8: <= 120) per SIMD, LDS 160 KiB / lds
+    const long by_regs = R1 == 16 ? 8 : 16, by_lds = (160 * 1024) / (long)lds;
     long per_cu = by_lds < by_regs ? by_lds : by_regs;
     if (per_cu > 4) per_cu -= per_cu % 4;    // the same number of wavefronts on each of the CU's four SIMDs (measured: 9 per CU is slower than 8)
     // tuning experiments (DDSP_TEST_HOOKS=1 processes only; read once)

@@ -393,6 +393,48 @@ def test_noise_fft_backward_equals_direct_backward(nf, injected):
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("hop,nf", [(128, 65), (512, 257), (512, 195), (256, 129)])
+def test_noise_error_is_relative_to_each_frames_own_level(hop, nf):
+    """The reference transforms every frame alone (filtered_noise.py:7-32), so a quiet frame next to a loud one keeps its own
+    relative accuracy.  The hop-512 form transforms two frames as one complex sequence: it equalises them by powers of two first
+    (csrc/ddsp_noise_fft.hip: frame_scale).  Frame levels spread over seven decades, one exactly-zero frame, an odd number
+    of frames per row; error per frame against the C oracle, relative to the frame's own peak."""
+    rng = np.random.default_rng(4100 + hop + nf)
+    B, T = 3, 21
+    level = (10.0 ** rng.uniform(-4, 3, size=(B, T, 1))).astype(np.float32)
+    Hm = syn.controller_range(rng.standard_normal((B, T, nf), dtype=np.float32)) * level
+    Hm[1, 4] = 0.0
+    u = rng.random((B, T, hop), dtype=np.float32)
+    ref = oracle.noise_forward(Hm, u, hop).reshape(B, T, hop)
+    got = ddsp.noise_forward(dev(Hm), hop, uniform=dev(u)).cpu().numpy().reshape(B, T, hop)
+    peak = np.abs(ref).max(axis=2)
+    err = np.abs(got - ref).max(axis=2)
+    assert np.all(got[1, 4] == 0.0)
+    assert np.all(err <= 2e-6 * np.maximum(peak, level[:, :, 0])), float(np.max(err / np.maximum(peak, level[:, :, 0])))
+
+
+def test_noise_fft_backward_error_is_relative_to_each_rows_own_level():
+    """As above for the hop-512 backward: upstream gradient rows of very different size share a transform pair; each frame's
+    dH against the direct (per-frame) backward, relative to that frame's own largest gradient."""
+    rng = np.random.default_rng(4200)
+    B, T, hop, nf = 3, 7, 512, 257
+    level = (10.0 ** rng.uniform(-4, 3, size=(B, T, 1))).astype(np.float32)
+    gy = (rng.standard_normal((B, T, hop)).astype(np.float32) * level).reshape(B, T * hop)
+    gy[2, 3 * hop:4 * hop] = 0.0
+    kw = dict(seed=77, offset=(3 << 32) + 1)
+    L = ddsp._lib.lib()
+    got = ddsp.noise_backward(dev(gy), hop, nf, **kw).cpu().numpy()
+    L.ddsp_noise_set_generic(2)
+    try:
+        ref = ddsp.noise_backward(dev(gy), hop, nf, **kw).cpu().numpy()
+    finally:
+        L.ddsp_noise_set_generic(0)
+    peak = np.abs(ref).max(axis=2)
+    err = np.abs(got - ref).max(axis=2)
+    assert np.all(got[2, 3] == 0.0)
+    assert np.all(err <= 1e-5 * np.maximum(peak, 1e-30)), float(np.max(err / np.maximum(peak, 1e-30)))
+
+
 def test_osc_grad_vs_torch_restatement_bigger():
     # autograd of the torch-op restatement (CPU, same ops as the reference) on a cfg2-shaped slice incl. masked harmonics
     from oracle import torch_restatement as tr
