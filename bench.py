@@ -251,10 +251,13 @@ def train_mode(args, rank, world, dist):
             "slowest_rank": int(np.argmax(per_rank[:, 0])),
             "collective_backend": dist.get_backend() if dist is not None else None,
             "rccl_ranks": dist.get_world_size() if dist is not None else 1,
-            "final_loss": float(loss)}), flush=True)
+            "final_loss": float(loss)}), file=RESULT, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+RESULT = sys.stdout     # where the ONE JSON line goes (main() moves everything else that writes to fd 1 over to stderr)
 
 
 def main():
@@ -287,6 +290,12 @@ def main():
     ap.add_argument("--noise", default="device", choices=["device", "resident"],
                     help="uniform draw: in-kernel Philox, or a [B,T,hop] tensor already resident in HBM")
     args = ap.parse_args()
+    # libraries print to stdout on their own (gloo's "[Gloo] Rank 0 is connected ..." at the first collective): from here on
+    # fd 1 is stderr for everybody, and only the result line goes to the real stdout
+    global RESULT
+    sys.stdout.flush()
+    RESULT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -441,7 +450,7 @@ def main():
                                "cfg2": time_config(syn.CFG2, 1002, 10, 2), "cfg3": time_config(syn.CFG3, 1003, 10, 2)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(shape)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=RESULT, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
