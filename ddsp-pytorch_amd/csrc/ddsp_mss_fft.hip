@@ -76,8 +76,14 @@ struct WaveUnit {
     static constexpr int BINS = N / 2 + 1;
 };
 
+// wavefronts per SIMD the register allocation aims at: up to 256 points four (128 VGPRs; left alone the compiler took 132 and 141
+// for 128 and 256 points -- three wavefronts -- which measured 38.5 / 39.2 us against 33.9 / 35.5 us with a handful of spilled
+// registers); 512 points three (four would spill 49 registers: no gain), 1024 two (three: 168 VGPRs without a spill but slower)
+#ifndef MSS_WAVES
+#define MSS_WAVES(n) ((n) <= 256 ? 4 : ((n) <= 512 ? 3 : 2))
+#endif
 template <int N>
-__global__ void __launch_bounds__(64) mss_wave_kernel(MssParams p, long nunits)
+__global__ void __launch_bounds__(64, MSS_WAVES(N)) mss_wave_kernel(MssParams p, long nunits)
 {
     using U = WaveUnit<N>;
     using ddsp_wfft::cf;

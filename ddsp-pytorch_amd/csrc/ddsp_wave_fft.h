@@ -137,20 +137,23 @@ __device__ __forceinline__ void make_twiddles(Twiddles<R1> &tw, int lane)
     }
 }
 
-// Exchange addresses (in float2 units inside one buffer of buf_elems<R1>() elements).  Both are LINEAR in their
-// arguments -- lane-dependent base + compile-time offset, so the unrolled loops address LDS with immediates -- and padded
-// so that b64 accesses do not collide on banks:
-// step 1 -> 2: element (k1, n2, n3) at ROW1 n2 + (R1 + 1) n3 + k1.  The 16 lanes of a b64 write group (two n2, eight n3,
-// one k1) differ by (R1 + 1) n3 + ROW1 (n2 & 1) = 16 different residues mod 16 (ROW1 = 136: 8 mod 16; 81: 1 mod 16);
-// the step-2 reads (lanes k1 + R1 m) are consecutive apart from one pad per R1 lanes (at most a 2-way conflict).
-template <int R1> struct Rows { static constexpr int r1 = (R1 == 16) ? 136 : 81, r2 = (R1 == 16) ? 128 : 72; };
+// Exchange addresses (in float2 units inside one buffer of buf_elems<R1>() elements).  Both are SEPARABLE in their arguments --
+// lane-dependent base + compile-time offset, so the unrolled loops address LDS with immediates -- and laid out so that b64
+// accesses do not collide on banks (a b64 access of 32 lanes covers the 64 banks once):
+// step 1 -> 2, R1 = 16: element (k1, n2, n3) at 136 n2 + 17 n3 + k1.  A write (lanes (n2, n3), one k1) touches
+//   8 n2 + 17 n3 mod 32: 32 different residues; the step-2 reads (lanes k1 + 16 m) are consecutive apart from one pad per 16 lanes.
+// step 1 -> 2, R1 = 8: element (k1, n2, n3) at 68 k1 + 8 n2 + n3.  A write (lanes 8 n2 + n3, one k1) is 64 CONSECUTIVE elements;
+//   a step-2 read (lanes k1 + 8 n3, one n2) touches 4 k1 + n3 mod 32: 32 different residues per half wavefront.  (Rounds 2-3 used
+//   81 n2 + 9 n3 + k1 here: both its writes and its reads were two-way conflicted -- a quarter to a third of the LDS cycles of the
+//   spectral-loss scales below 1024 points, profiles/r03_mss_pmc.json.)
 template <int R1>
-__device__ __forceinline__ int addr1(int k1, int n2, int n3) { return Rows<R1>::r1 * n2 + (R1 + 1) * n3 + k1; }
-// step 2 -> 3: element (c = k1 + R1 k2, n3) at ROW2 n3 + c (R1 = 8: 72 = 8 mod 16 separates the two n3 of a write group)
+__device__ __forceinline__ int addr1(int k1, int n2, int n3) { return (R1 == 16) ? 136 * n2 + 17 * n3 + k1 : 68 * k1 + 8 * n2 + n3; }
+// step 2 -> 3: element (c = k1 + R1 k2, n3) at ROW2 n3 + c (R1 = 8: 72 = 8 mod 32 puts the four n3 of a half-wavefront write on
+// different banks; R1 = 16: 128, the writes of a half wavefront are 2 x 16 consecutive elements 128 apart ... see fft_wave)
 template <int R1>
-__device__ __forceinline__ int addr2(int c, int n3) { return Rows<R1>::r2 * n3 + c; }
+__device__ __forceinline__ int addr2(int c, int n3) { return ((R1 == 16) ? 128 : 72) * n3 + c; }
 template <int R1>
-constexpr int buf_elems() { return 8 * Rows<R1>::r1 > 64 * R1 ? 8 * Rows<R1>::r1 : 64 * R1; }
+constexpr int buf_elems() { return (R1 == 16) ? 8 * 136 : 576; }
 
 // 64*R1-point complex FFT of the wavefront's data.  In: v[n1] = x[64 n1 + lane].  Out: v[d * 8 + k3] = X[c + 8 R1 k3] with
 // c = lane + 64 d (d < R1/8).  `buf`: N float2 of LDS, free to clobber.
