@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include <initializer_list>
+
 #include "ddsp_hip.h"
 
 namespace {
@@ -228,6 +230,154 @@ __global__ void __launch_bounds__(1024) ln_lrelu_finish_kernel(const float *__re
     }
 }
 
+// ---- the FIRST block of the f0 / loudness stacks (decoder.py:43-44: Linear(1 -> D) -> LayerNorm -> LeakyReLU) --------------------
+// Its Linear is an outer product x[row] * w[j] + b[j]: the row is rebuilt from ONE scalar instead of being written by an elementwise
+// pass and read back, forward and backward; and since the block's input carries no gradient, the backward does not store d x either:
+// d w[j] = sum_rows dx[row][j] * x[row] and d b[j] = sum_rows dx[row][j] are accumulated beside d gamma / d beta (four column
+// sums per workgroup, the same finish).  Replaces, per stack and step: addcmul + fp32 LayerNorm pass forward; fp32 LayerNorm backward,
+// two stock reductions of [rows, D] (24 us each) and a product pass backward.
+template <int NV, typename IO>
+__global__ void __launch_bounds__(256) outer_ln_lrelu_fwd_kernel(const float *__restrict__ xs, const float *__restrict__ w,
+                                                                 const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                                 const float *__restrict__ beta, typename IO::T *__restrict__ y,
+                                                                 float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                                                 long rows, float eps, float slope)
+{
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    float4 g[NV], b[NV], wv[NV], bv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        g[j] = reinterpret_cast<const float4 *>(gamma)[lane + 64 * j];
+        b[j] = reinterpret_cast<const float4 *>(beta)[lane + 64 * j];
+        wv[j] = reinterpret_cast<const float4 *>(w)[lane + 64 * j];
+        bv[j] = reinterpret_cast<const float4 *>(bias)[lane + 64 * j];
+    }
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+        const float xr = xs[row];
+        float4 v[NV];
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v[j] = make_float4(xr * wv[j].x + bv[j].x, xr * wv[j].y + bv[j].y, xr * wv[j].z + bv[j].z, xr * wv[j].w + bv[j].w);   // product, then sum: a K = 1 GEMM
+            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+        const float mean = wave_sum64(s) * (1.0f / D);
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+            q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum64(q) * (1.0f / D) + eps);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            float4 o;
+            o.x = __fmaf_rn(v[j].x * rstd, g[j].x, b[j].x);
+            o.y = __fmaf_rn(v[j].y * rstd, g[j].y, b[j].y);
+            o.z = __fmaf_rn(v[j].z * rstd, g[j].z, b[j].z);
+            o.w = __fmaf_rn(v[j].w * rstd, g[j].w, b[j].w);
+            o.x = o.x > 0.0f ? o.x : o.x * slope;
+            o.y = o.y > 0.0f ? o.y : o.y * slope;
+            o.z = o.z > 0.0f ? o.z : o.z * slope;
+            o.w = o.w > 0.0f ? o.w : o.w * slope;
+            IO::st(y + row * D, lane + 64 * j, o);
+        }
+        if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    }
+}
+
+// partials: [gridDim.x][4][D]  (d gamma | d beta | d w | d b)
+template <int NV, typename IO>
+__global__ void __launch_bounds__(256) outer_ln_lrelu_bwd_kernel(const typename IO::T *__restrict__ gy, const float *__restrict__ xs,
+                                                                 const float *__restrict__ w, const float *__restrict__ bias,
+                                                                 const typename IO::T *__restrict__ y, const float *__restrict__ gamma,
+                                                                 const float *__restrict__ mean_in, const float *__restrict__ rstd_in,
+                                                                 float *__restrict__ partials, long rows, float slope)
+{
+    constexpr int D = 256 * NV;
+    __shared__ float red[4][4][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 g[NV], wv[NV], bv[NV], dg[NV], db[NV], dw[NV], dc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        g[j] = reinterpret_cast<const float4 *>(gamma)[lane + 64 * j];
+        wv[j] = reinterpret_cast<const float4 *>(w)[lane + 64 * j];
+        bv[j] = reinterpret_cast<const float4 *>(bias)[lane + 64 * j];
+        dg[j] = db[j] = dw[j] = dc[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const float mean = mean_in[row], rstd = rstd_in[row], xr = xs[row];
+        float4 xh[NV], d[NV];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const float4 xv = make_float4(xr * wv[j].x + bv[j].x, xr * wv[j].y + bv[j].y, xr * wv[j].z + bv[j].z, xr * wv[j].w + bv[j].w);
+            const float4 yv = IO::ld(y + row * D, lane + 64 * j);
+            float4 gv = IO::ld(gy + row * D, lane + 64 * j);
+            gv.x = yv.x > 0.0f ? gv.x : gv.x * slope;
+            gv.y = yv.y > 0.0f ? gv.y : gv.y * slope;
+            gv.z = yv.z > 0.0f ? gv.z : gv.z * slope;
+            gv.w = yv.w > 0.0f ? gv.w : gv.w * slope;
+            xh[j] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+            dg[j].x += gv.x * xh[j].x; dg[j].y += gv.y * xh[j].y; dg[j].z += gv.z * xh[j].z; dg[j].w += gv.w * xh[j].w;
+            db[j].x += gv.x; db[j].y += gv.y; db[j].z += gv.z; db[j].w += gv.w;
+            d[j] = make_float4(gv.x * g[j].x, gv.y * g[j].y, gv.z * g[j].z, gv.w * g[j].w);
+            s1 += (d[j].x + d[j].y) + (d[j].z + d[j].w);
+            s2 += (d[j].x * xh[j].x + d[j].y * xh[j].y) + (d[j].z * xh[j].z + d[j].w * xh[j].w);
+        }
+        const float m1 = wave_sum64(s1) * (1.0f / D), m2 = wave_sum64(s2) * (1.0f / D);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            float4 o;                                              // d (pre-activation): never stored
+            o.x = rstd * (d[j].x - m1 - xh[j].x * m2);
+            o.y = rstd * (d[j].y - m1 - xh[j].y * m2);
+            o.z = rstd * (d[j].z - m1 - xh[j].z * m2);
+            o.w = rstd * (d[j].w - m1 - xh[j].w * m2);
+            dw[j].x += o.x * xr; dw[j].y += o.y * xr; dw[j].z += o.z * xr; dw[j].w += o.w * xr;
+            dc[j].x += o.x; dc[j].y += o.y; dc[j].z += o.z; dc[j].w += o.w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        reinterpret_cast<float4 *>(red[wave][0])[lane + 64 * j] = dg[j];
+        reinterpret_cast<float4 *>(red[wave][1])[lane + 64 * j] = db[j];
+        reinterpret_cast<float4 *>(red[wave][2])[lane + 64 * j] = dw[j];
+        reinterpret_cast<float4 *>(red[wave][3])[lane + 64 * j] = dc[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * D; i += 256) {
+        const int which = i / D, c = i - which * D;
+        partials[((size_t)blockIdx.x * 4 + which) * D + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+}
+
+// columns of the [blocks][4*D] partial slabs -> d gamma | d beta | d w | d b (the two-output finish above, four outputs)
+__global__ void __launch_bounds__(1024) outer_ln_finish_kernel(const float *__restrict__ partials, int blocks, int D,
+                                                               float *__restrict__ o0, float *__restrict__ o1, float *__restrict__ o2, float *__restrict__ o3)
+{
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;   // c over 4 * D columns
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int b = grp;
+    for (; b + 48 < blocks; b += 64) {
+        s0 += partials[(size_t)b * 4 * D + c];
+        s1 += partials[(size_t)(b + 16) * 4 * D + c];
+        s2 += partials[(size_t)(b + 32) * 4 * D + c];
+        s3 += partials[(size_t)(b + 48) * 4 * D + c];
+    }
+    for (; b < blocks; b += 16) s0 += partials[(size_t)b * 4 * D + c];
+    red[grp][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x & 63];
+        const int which = c / D, cc = c - which * D;
+        (which == 0 ? o0 : which == 1 ? o1 : which == 2 ? o2 : o3)[cc] = t;
+    }
+}
+
 constexpr int kLnBlocks = 1024;  // four workgroups per CU: enough rows in flight to cover the HBM latency
 
 }  // namespace
@@ -316,6 +466,76 @@ extern "C" int ddsp_ln_lrelu_backward_16(const void *grad_y, const void *x, cons
     hipStream_t s = (hipStream_t)stream;
     if (io_type == DDSP_IO_BF16) return ln_backward<IoBf16>(grad_y, x, y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, scratch, rows, D, slope, s);
     if (io_type == DDSP_IO_F16) return ln_backward<IoF16>(grad_y, x, y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, scratch, rows, D, slope, s);
+    return DDSP_EINVAL;
+}
+
+namespace {
+
+template <typename IO>
+int outer_forward(const float *xs, const float *w, const float *bias, const float *gamma, const float *beta, void *y, float *mean,
+                  float *rstd, long rows, int D, float eps, float slope, hipStream_t s)
+{
+    if (rows == 0) return 0;
+    if (!xs || !w || !bias || !gamma || !beta || !y || !mean || !rstd || rows < 0) return DDSP_EINVAL;
+    if (D != 256 && D != 512) return DDSP_ERANGE;            // (the backward keeps 16 floats of LDS per column and wavefront)
+    typedef typename IO::T T;
+    T *yo = (T *)y;
+    const long want = (rows + 3) / 4;
+    const dim3 grid((unsigned)(want < 4096 ? want : 4096)), blk(256);
+    if (D == 256) hipLaunchKernelGGL((outer_ln_lrelu_fwd_kernel<1, IO>), grid, blk, 0, s, xs, w, bias, gamma, beta, yo, mean, rstd, rows, eps, slope);
+    else hipLaunchKernelGGL((outer_ln_lrelu_fwd_kernel<2, IO>), grid, blk, 0, s, xs, w, bias, gamma, beta, yo, mean, rstd, rows, eps, slope);
+    return (int)hipGetLastError();
+}
+
+template <typename IO>
+int outer_backward(const void *grad_y, const float *xs, const float *w, const float *bias, const void *y, const float *gamma,
+                   const float *mean, const float *rstd, float *grad_w, float *grad_b, float *grad_gamma, float *grad_beta,
+                   void *scratch, long rows, int D, float slope, hipStream_t s)
+{
+    if (D != 256 && D != 512) return DDSP_ERANGE;
+    if (!grad_w || !grad_b || !grad_gamma || !grad_beta) return DDSP_EINVAL;
+    if (rows == 0) {   // an empty shard: the parameter gradients are zero
+        hipError_t e = hipSuccess;
+        for (float *o : {grad_w, grad_b, grad_gamma, grad_beta})
+            if (e == hipSuccess) e = hipMemsetAsync(o, 0, sizeof(float) * (size_t)D, s);
+        return (int)e;
+    }
+    if (!grad_y || !xs || !w || !bias || !y || !gamma || !mean || !rstd || !scratch || rows < 0) return DDSP_EINVAL;
+    typedef typename IO::T T;
+    const T *gy = (const T *)grad_y, *yi = (const T *)y;
+    const long want = (rows + 3) / 4;
+    const int blocks = (int)(want < kLnBlocks ? want : kLnBlocks);
+    const dim3 grid((unsigned)blocks), blk(256);
+    float *part = (float *)scratch;
+    if (D == 256) hipLaunchKernelGGL((outer_ln_lrelu_bwd_kernel<1, IO>), grid, blk, 0, s, gy, xs, w, bias, yi, gamma, mean, rstd, part, rows, slope);
+    else hipLaunchKernelGGL((outer_ln_lrelu_bwd_kernel<2, IO>), grid, blk, 0, s, gy, xs, w, bias, yi, gamma, mean, rstd, part, rows, slope);
+    hipLaunchKernelGGL(outer_ln_finish_kernel, dim3((unsigned)(4 * D / 64)), dim3(1024), 0, s, part, blocks, D, grad_gamma, grad_beta, grad_w, grad_b);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" size_t ddsp_outer_ln_lrelu_scratch_bytes(int D) { return D > 0 ? sizeof(float) * 4 * (size_t)D * kLnBlocks : 0; }
+
+extern "C" int ddsp_outer_ln_lrelu_forward(const float *x, const float *w, const float *bias, const float *gamma, const float *beta, void *y,
+                                           float *mean, float *rstd, long rows, int D, float eps, float slope, int io_type, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (io_type == 0) return outer_forward<IoF32>(x, w, bias, gamma, beta, y, mean, rstd, rows, D, eps, slope, s);
+    if (io_type == DDSP_IO_BF16) return outer_forward<IoBf16>(x, w, bias, gamma, beta, y, mean, rstd, rows, D, eps, slope, s);
+    if (io_type == DDSP_IO_F16) return outer_forward<IoF16>(x, w, bias, gamma, beta, y, mean, rstd, rows, D, eps, slope, s);
+    return DDSP_EINVAL;
+}
+
+extern "C" int ddsp_outer_ln_lrelu_backward(const void *grad_y, const float *x, const float *w, const float *bias, const void *y,
+                                            const float *gamma, const float *mean, const float *rstd, float *grad_w, float *grad_bias,
+                                            float *grad_gamma, float *grad_beta, void *scratch, long rows, int D, float slope,
+                                            int io_type, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (io_type == 0) return outer_backward<IoF32>(grad_y, x, w, bias, y, gamma, mean, rstd, grad_w, grad_bias, grad_gamma, grad_beta, scratch, rows, D, slope, s);
+    if (io_type == DDSP_IO_BF16) return outer_backward<IoBf16>(grad_y, x, w, bias, y, gamma, mean, rstd, grad_w, grad_bias, grad_gamma, grad_beta, scratch, rows, D, slope, s);
+    if (io_type == DDSP_IO_F16) return outer_backward<IoF16>(grad_y, x, w, bias, y, gamma, mean, rstd, grad_w, grad_bias, grad_gamma, grad_beta, scratch, rows, D, slope, s);
     return DDSP_EINVAL;
 }
 

@@ -88,6 +88,56 @@ class _LayerNormLeakyReLU(torch.autograd.Function):
         return gx, dg.to(ctx.param_dtypes[0]), db.to(ctx.param_dtypes[1]), None, None
 
 
+class _FirstBlock(torch.autograd.Function):
+    """Linear(1 -> D) -> LayerNorm -> LeakyReLU, the first block of the f0 / loudness stacks (decoder.py:43-44), as one HIP pass
+    each way (include/ddsp_hip.h: ddsp_outer_ln_lrelu_*): the [rows, D] pre-activation is rebuilt from the ONE input feature
+    instead of being written and read back, and the backward sums the Linear's weight / bias gradients beside the LayerNorm's
+    -- the input carries no gradient (the caller checks).  Output in the autocast dtype when autocast is on, fp32 otherwise."""
+
+    _IO = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, eps, slope):
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+        if dt not in _FirstBlock._IO:
+            dt = torch.float32
+        D = weight.shape[0]
+        xs = x.detach().reshape(-1).contiguous().float()
+        rows = xs.numel()
+        w, c = weight.detach().reshape(-1).contiguous().float(), bias.detach().contiguous().float()
+        g, b = gamma.detach().contiguous().float(), beta.detach().contiguous().float()
+        y = torch.empty(x.shape[:-1] + (D,), device=x.device, dtype=dt)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ddsp_outer_ln_lrelu_forward(xs.data_ptr(), w.data_ptr(), c.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                                              mean.data_ptr(), rstd.data_ptr(), rows, D, float(eps), float(slope),
+                                                              _FirstBlock._IO[dt], torch.cuda.current_stream().cuda_stream),
+                       "ddsp_outer_ln_lrelu_forward")
+        ctx.save_for_backward(xs, w, c, y, g, mean, rstd)
+        ctx.slope = float(slope)
+        ctx.param_meta = (weight.shape, weight.dtype, bias.dtype, gamma.dtype, beta.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xs, w, c, y, g, mean, rstd = ctx.saved_tensors
+        D = w.numel()
+        rows = xs.numel()
+        gy = gy.contiguous().to(y.dtype)
+        out = torch.empty((4, D), device=y.device, dtype=torch.float32)        # d w | d bias | d gamma | d beta
+        L = _lib.lib()
+        scratch = torch.empty(L.ddsp_outer_ln_lrelu_scratch_bytes(D), device=y.device, dtype=torch.uint8)
+        with torch.cuda.device(y.device):
+            _lib.check(L.ddsp_outer_ln_lrelu_backward(gy.data_ptr(), xs.data_ptr(), w.data_ptr(), c.data_ptr(), y.data_ptr(), g.data_ptr(),
+                                                      mean.data_ptr(), rstd.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                                      out[2].data_ptr(), out[3].data_ptr(), scratch.data_ptr(), rows, D, ctx.slope,
+                                                      _FirstBlock._IO[y.dtype], torch.cuda.current_stream().cuda_stream),
+                       "ddsp_outer_ln_lrelu_backward")
+        wshape, wdt, cdt, gdt, bdt = ctx.param_meta
+        return None, out[0].view(wshape).to(wdt), out[1].to(cdt), out[2].to(gdt), out[3].to(bdt), None, None
+
+
 # Under torch.autocast the Linear layers hand over bf16 / fp16 activations: the fused LayerNorm pass reads and writes
 # them as they are; the head non-linearity converts (`custom_fwd(cast_inputs=float32)`) and returns fp32.
 _FUSED_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
@@ -96,6 +146,12 @@ _FUSED_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
 def _run_stack(stack: nn.Module, x: torch.Tensor) -> torch.Tensor:
     for i in range(stack.depth):
         linear, norm, act = getattr(stack, f"mlp_layer{i + 1}")
+        if (linear.in_features == 1 and linear.bias is not None and x.is_cuda and not x.requires_grad and x.shape[-1] == 1
+                and linear.out_features in (256, 512) and norm.elementwise_affine and norm.bias is not None and act.negative_slope > 0
+                and linear.weight.dtype == torch.float32):
+            # decoder.py:43-44: the f0 / loudness stacks start from ONE feature -- the whole block is one pass each way
+            x = _FirstBlock.apply(x, linear.weight, linear.bias, norm.weight, norm.bias, norm.eps, act.negative_slope)
+            continue
         if linear.in_features == 1 and linear.bias is not None and x.is_cuda:
             # decoder.py:43-44: the f0 / loudness stacks start from ONE feature -- an outer product, not a GEMM (as a
             # library GEMM with K = 1 it costs 0.16 ms in fp32 and 11 ms of host time per call in bf16 on this stack):

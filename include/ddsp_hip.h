@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_ABI_VERSION 2
+#define DDSP_HIP_ABI_VERSION 3
 
 #define DDSP_EINVAL (-1)   /* null pointer / non-positive size */
 #define DDSP_ERANGE (-2)   /* shape outside what the kernels are built for */
@@ -178,6 +178,22 @@ int ddsp_gru_backward_bf16(const float *dy, const float *dhT, const float *w_hh,
  * spin bound drops to 20 ms, so that the time-out path (status word, NaN in every unfinished output) can be tested. */
 int ddsp_gru_set_mode(int mode);
 int ddsp_gru_set_fault_step(int step);
+
+/*
+ * The FIRST block of the f0 / loudness stacks (model/autoencoder/decoder.py:9-39 with n_input = 1, :43-44):
+ * Linear(1 -> D) -> LayerNorm -> LeakyReLU as one pass each way.  x [rows] fp32 (the one input feature), w [D] (the Linear's
+ * [D, 1] weight), bias [D]; y [rows, D] in io_type (0 fp32, DDSP_IO_BF16, DDSP_IO_F16); mean / rstd [rows] kept for the backward.
+ * The backward returns the four parameter gradients (fp32, deterministically summed) and NO input gradient -- callers whose
+ * x requires one use the separate Linear and ddsp_ln_lrelu_*.  D = 256 or 512 (DDSP_ERANGE otherwise).
+ * scratch >= ddsp_outer_ln_lrelu_scratch_bytes(D).
+ */
+size_t ddsp_outer_ln_lrelu_scratch_bytes(int D);
+int ddsp_outer_ln_lrelu_forward(const float *x, const float *w, const float *bias, const float *gamma, const float *beta, void *y,
+                                float *mean, float *rstd, long rows, int D, float eps, float slope, int io_type, void *stream);
+int ddsp_outer_ln_lrelu_backward(const void *grad_y, const float *x, const float *w, const float *bias, const void *y,
+                                 const float *gamma, const float *mean, const float *rstd, float *grad_w, float *grad_bias,
+                                 float *grad_gamma, float *grad_beta, void *scratch, long rows, int D, float slope,
+                                 int io_type, void *stream);
 
 /*
  * Column sums of a row-major [M, N] matrix (fp32 io_type 0, bf16 DDSP_IO_BF16, fp16 DDSP_IO_F16) -> out [N] fp32: the bias

@@ -370,6 +370,62 @@ def test_fused_layernorm_leakyrelu_matches_torch_layers(D):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D", [256, 512])
+@pytest.mark.parametrize("amp", [None, torch.bfloat16, torch.float16])
+def test_first_block_of_the_f0_and_loudness_stacks_matches_torch_layers(D, amp):
+    """decoder.py:43-44: Linear(1 -> D) -> LayerNorm -> LeakyReLU as ONE HIP pass each way (decoder._FirstBlock) against the stock
+    layers on the CPU in fp32 -- output and all parameter gradients.  Under autocast the output is 16-bit (as F.linear's would be):
+    there the yardstick is the SEPARATE-layer GPU path under the same autocast (taken when the input asks for a gradient), whose
+    distance from the fp32 reference the fused pass must not exceed by more than a factor."""
+    from ddsp_pytorch_amd.decoder import _dense_stack, _run_stack
+    torch.manual_seed(D)
+    stack = _dense_stack(1, D, 2)
+    with torch.no_grad():
+        for i in (1, 2):
+            ln = getattr(stack, f"mlp_layer{i}")[1]
+            ln.weight.uniform_(0.5, 1.5)
+            ln.bias.uniform_(-0.3, 0.3)
+    x0 = torch.rand(3, 41, 1) * 2 - 1
+    wgt = torch.randn(3, 41, D)
+
+    def run(mod, dev, separate=False):
+        mod = mod.to(dev)
+        for p in mod.parameters():
+            p.grad = None
+        x = x0.clone().to(dev).requires_grad_(separate)
+        with torch.autocast("cuda", dtype=amp, enabled=(amp is not None and dev == "cuda")):
+            y = _run_stack(mod, x)
+        (y.float() * wgt.to(dev)).sum().backward()
+        return y.detach().float().cpu(), {k: p.grad.detach().float().cpu().clone() for k, p in mod.named_parameters()}
+
+    y_ref, gp_ref = run(stack, "cpu")
+    y, gp = run(stack, "cuda")
+    assert set(gp) == set(gp_ref) and all(g.isfinite().all() for g in gp.values())
+    if amp is None:
+        assert float((y - y_ref).abs().max()) <= 1e-5 * max(1.0, float(y_ref.abs().max()))
+        for k in gp_ref:
+            assert float((gp[k] - gp_ref[k]).abs().max()) <= 1e-4 * (float(gp_ref[k].abs().max()) + 1e-9), k
+        return
+    y_sep, gp_sep = run(stack, "cuda", separate=True)
+    unit = 2.0 ** -8 if amp == torch.bfloat16 else 2.0 ** -11
+    assert float((y - y_ref).abs().max()) <= 2.0 * float((y_sep - y_ref).abs().max()) + unit * float(y_ref.abs().max())
+    for k in gp_ref:
+        scale = float(gp_ref[k].abs().max()) + 1e-9
+        assert float((gp[k] - gp_ref[k]).abs().max()) <= 2.0 * float((gp_sep[k] - gp_ref[k]).abs().max()) + unit * scale, k
+
+
+@pytest.mark.gpu
+def test_first_block_falls_back_when_its_input_needs_a_gradient():
+    """_FirstBlock returns no input gradient: an input that requires one takes the separate layers (and gets it)."""
+    from ddsp_pytorch_amd.decoder import _dense_stack, _run_stack
+    torch.manual_seed(3)
+    stack = _dense_stack(1, 256, 1).cuda()
+    x = torch.rand(2, 9, 1, device="cuda", requires_grad=True)
+    _run_stack(stack, x).sum().backward()
+    assert x.grad is not None and bool(x.grad.isfinite().all()) and float(x.grad.abs().max()) > 0
+
+
+@pytest.mark.gpu
 def test_graphed_live_decoder_equals_eager_callbacks():
     """The whole rt callback as one hipGraph (GraphedLiveDecoder) against `Decoder.forward_live` called eagerly: same audio
     for three consecutive callbacks -- oscillator phases, reverb history and the noise stream are carried inside the graph."""
