@@ -287,6 +287,8 @@ def main():
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (with --backend gloo), instead of cuda:LOCAL_RANK")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: initialise the process group (and run every collective of the N > 1 path) with ONE rank too")
     ap.add_argument("--noise", default="device", choices=["device", "resident"],
                     help="uniform draw: in-kernel Philox, or a [B,T,hop] tensor already resident in HBM")
     args = ap.parse_args()
@@ -308,8 +310,13 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:                    # a lone rank started without a launcher
+            sock = socket.socket()
+            sock.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sock.getsockname()[1]), RANK="0", WORLD_SIZE="1")
+            sock.close()
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:

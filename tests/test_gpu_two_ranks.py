@@ -156,3 +156,24 @@ def test_bench_train_mode_two_ranks_times_the_allreduce():
     line = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")][0]
     assert line["n_gpus"] == 2 and line["allreduce_ms"] > 0 and line["config"]["allreduce_bytes"] > 0
     assert len(line["per_rank_ms"]) == 2 and len(line["per_rank_allreduce_ms"]) == 2 and line["rccl_ranks"] == 2
+
+
+@pytest.mark.parametrize("mode", ["synth", "train"])
+def test_bench_one_rank_through_rccl(mode):
+    """The collectives of the N > 1 path on the backend the driver's multi-GPU runs use (`nccl` = RCCL), with the one rank this box
+    allows (RCCL refuses two ranks on one device): process-group init bound to the device, barriers, the MAX / SUM all-reduces of
+    the timing and the diagnostics, and -- train mode -- the flat gradient bucket's all-reduce.  What stays unmeasured is only what
+    needs a second GPU: the xGMI transfers themselves."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    args = ["--mode", "train", "--batch", "2", "--steps", "2", "--warmup", "1"] if mode == "train" else ["--batch", "16", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--force-dist",
+                        "--no-cpu-baseline", "--no-secondary"] + args, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 1 and line["collective_backend"] == "nccl" and line["rccl_ranks"] == 1
+    assert line["value"] > 0 and len(line["per_rank_ms"]) == 1 and line["per_rank_ms"][0] > 0
+    if mode == "train":
+        assert line["allreduce_ms"] > 0 and line["config"]["allreduce_bytes"] > 0
