@@ -382,10 +382,18 @@ __global__ void __launch_bounds__(256) osc_supscan_kernel(OscParams p)
     const int b = (int)(idx / p.H), h = (int)(idx - (long)b * p.H);
     double *col = p.sup + (long)b * p.NSB * p.H + h;
     double run = 0.0;
-    for (int s = 0; s < p.NSB; ++s) {
-        const double v = col[(long)s * p.H];
-        col[(long)s * p.H] = run;
-        run += v;
+    // sixteen totals per round trip: read first, then write (one load -> store -> load chain per superblock was 0.6 us each:
+    // 11 us for the 16 superblocks of a 4 s clip); the additions keep their order, so the sums keep their bits
+    for (int s0 = 0; s0 < p.NSB; s0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (s0 + i < p.NSB) ? col[(long)(s0 + i) * p.H] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (s0 + i < p.NSB) {
+                col[(long)(s0 + i) * p.H] = run;
+                run += v[i];
+            }
     }
 }
 
