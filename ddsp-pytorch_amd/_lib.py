@@ -104,11 +104,11 @@ def lib():
     L.ddsp_ln_lrelu_forward.restype = i32
     L.ddsp_ln_lrelu_forward.argtypes = [vp] * 6 + [ctypes.c_long, i32, ctypes.c_float, ctypes.c_float, vp]
     L.ddsp_ln_lrelu_backward.restype = i32
-    L.ddsp_ln_lrelu_backward.argtypes = [vp] * 10 + [ctypes.c_long, i32, ctypes.c_float, vp]
+    L.ddsp_ln_lrelu_backward.argtypes = [vp] * 11 + [ctypes.c_long, i32, ctypes.c_float, vp]
     L.ddsp_ln_lrelu_forward_16.restype = i32
     L.ddsp_ln_lrelu_forward_16.argtypes = [vp] * 6 + [ctypes.c_long, i32, ctypes.c_float, ctypes.c_float, i32, vp]
     L.ddsp_ln_lrelu_backward_16.restype = i32
-    L.ddsp_ln_lrelu_backward_16.argtypes = [vp] * 10 + [ctypes.c_long, i32, ctypes.c_float, i32, vp]
+    L.ddsp_ln_lrelu_backward_16.argtypes = [vp] * 11 + [ctypes.c_long, i32, ctypes.c_float, i32, vp]
     L.ddsp_outer_ln_lrelu_scratch_bytes.restype = ctypes.c_size_t
     L.ddsp_outer_ln_lrelu_scratch_bytes.argtypes = [i32]
     L.ddsp_outer_ln_lrelu_forward.restype = i32

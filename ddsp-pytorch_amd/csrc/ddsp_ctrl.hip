@@ -146,7 +146,8 @@ __global__ void __launch_bounds__(256) ln_lrelu_fwd_kernel(const typename IO::T 
     }
 }
 
-// partials: [gridDim.x][2][D]  (d gamma | d beta), one slab per workgroup, summed over its four wavefronts through LDS
+// partials: [gridDim.x][3][D]  (d gamma | d beta | column sums of d x = the bias gradient of the Linear in front), one slab per
+// workgroup, summed over its four wavefronts through LDS
 template <int NV, typename IO>
 __global__ void __launch_bounds__(256) ln_lrelu_bwd_kernel(const typename IO::T *__restrict__ gy, const typename IO::T *__restrict__ x,
                                                            const typename IO::T *__restrict__ y, const float *__restrict__ gamma,
@@ -154,13 +155,13 @@ __global__ void __launch_bounds__(256) ln_lrelu_bwd_kernel(const typename IO::T 
                                                            typename IO::T *__restrict__ gx, float *__restrict__ partials, long rows, float slope)
 {
     constexpr int D = 256 * NV;
-    __shared__ float red[4][2][D];
+    __shared__ float red[4][3][D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4 g[NV], dg[NV], db[NV];
+    float4 g[NV], dg[NV], db[NV], dc[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         g[j] = reinterpret_cast<const float4 *>(gamma)[lane + 64 * j];
-        dg[j] = db[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        dg[j] = db[j] = dc[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
         const float mean = mean_in[row], rstd = rstd_in[row];
@@ -191,42 +192,46 @@ __global__ void __launch_bounds__(256) ln_lrelu_bwd_kernel(const typename IO::T 
             o.z = rstd * (d[j].z - m1 - xh[j].z * m2);
             o.w = rstd * (d[j].w - m1 - xh[j].w * m2);
             IO::st(gx + row * D, lane + 64 * j, o);
+            dc[j].x += o.x; dc[j].y += o.y; dc[j].z += o.z; dc[j].w += o.w;
         }
     }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         reinterpret_cast<float4 *>(red[wave][0])[lane + 64 * j] = dg[j];
         reinterpret_cast<float4 *>(red[wave][1])[lane + 64 * j] = db[j];
+        reinterpret_cast<float4 *>(red[wave][2])[lane + 64 * j] = dc[j];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+    for (int i = threadIdx.x; i < 3 * D; i += 256) {
         const int which = i / D, c = i - which * D;
-        partials[((size_t)blockIdx.x * 2 + which) * D + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+        partials[((size_t)blockIdx.x * 3 + which) * D + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
     }
 }
 
-// columns of the [blocks][2*D] partial slabs -> d gamma | d beta; 64 columns x 16 row groups per workgroup, fixed order
+// columns of the [blocks][3*D] partial slabs -> d gamma | d beta | column sums (nullable); 64 columns x 16 row groups per workgroup, fixed order
 __global__ void __launch_bounds__(1024) ln_lrelu_finish_kernel(const float *__restrict__ partials, int blocks, int D,
-                                                               float *__restrict__ dgamma, float *__restrict__ dbeta)
+                                                               float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dxsum)
 {
     __shared__ float red[16][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;   // c over 2 * D columns
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;   // c over 3 * D columns
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;   // four loads in flight per thread
     int b = grp;
     for (; b + 48 < blocks; b += 64) {
-        s0 += partials[(size_t)b * 2 * D + c];
-        s1 += partials[(size_t)(b + 16) * 2 * D + c];
-        s2 += partials[(size_t)(b + 32) * 2 * D + c];
-        s3 += partials[(size_t)(b + 48) * 2 * D + c];
+        s0 += partials[(size_t)b * 3 * D + c];
+        s1 += partials[(size_t)(b + 16) * 3 * D + c];
+        s2 += partials[(size_t)(b + 32) * 3 * D + c];
+        s3 += partials[(size_t)(b + 48) * 3 * D + c];
     }
-    for (; b < blocks; b += 16) s0 += partials[(size_t)b * 2 * D + c];
+    for (; b < blocks; b += 16) s0 += partials[(size_t)b * 3 * D + c];
     red[grp][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp == 0) {
         float t = 0.0f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x & 63];
-        if (c < D) dgamma[c] = t; else dbeta[c - D] = t;
+        if (c < D) dgamma[c] = t;
+        else if (c < 2 * D) dbeta[c - D] = t;
+        else if (dxsum) dxsum[c - 2 * D] = t;
     }
 }
 
@@ -382,7 +387,7 @@ constexpr int kLnBlocks = 1024;  // four workgroups per CU: enough rows in fligh
 
 }  // namespace
 
-extern "C" size_t ddsp_ln_lrelu_scratch_bytes(int D) { return D > 0 ? sizeof(float) * 2 * (size_t)D * kLnBlocks : 0; }
+extern "C" size_t ddsp_ln_lrelu_scratch_bytes(int D) { return D > 0 ? sizeof(float) * 3 * (size_t)D * kLnBlocks : 0; }
 
 namespace {
 
@@ -409,13 +414,14 @@ int ln_forward(const void *x, const float *gamma, const float *beta, void *y, fl
 
 template <typename IO>
 int ln_backward(const void *grad_y, const void *x, const void *y, const float *gamma, const float *mean, const float *rstd, void *grad_x,
-                float *grad_gamma, float *grad_beta, void *scratch, long rows, int D, float slope, hipStream_t s)
+                float *grad_gamma, float *grad_beta, float *grad_xsum, void *scratch, long rows, int D, float slope, hipStream_t s)
 {
     if (D <= 0 || D % 256 != 0 || D > 1024) return DDSP_ERANGE;
     if (rows == 0) {   // an empty shard (batch < world size): no rows contribute, the parameter gradients are zero
         if (!grad_gamma || !grad_beta) return DDSP_EINVAL;
         hipError_t e = hipMemsetAsync(grad_gamma, 0, sizeof(float) * (size_t)D, s);
         if (e == hipSuccess) e = hipMemsetAsync(grad_beta, 0, sizeof(float) * (size_t)D, s);
+        if (e == hipSuccess && grad_xsum) e = hipMemsetAsync(grad_xsum, 0, sizeof(float) * (size_t)D, s);
         return (int)e;
     }
     if (!grad_y || !x || !y || !gamma || !mean || !rstd || !grad_x || !grad_gamma || !grad_beta || !scratch || rows < 0) return DDSP_EINVAL;
@@ -432,7 +438,7 @@ int ln_backward(const void *grad_y, const void *x, const void *y, const float *g
         case 3: hipLaunchKernelGGL((ln_lrelu_bwd_kernel<3, IO>), grid, blk, 0, s, gy, xi, yi, gamma, mean, rstd, gx, part, rows, slope); break;
         default: hipLaunchKernelGGL((ln_lrelu_bwd_kernel<4, IO>), grid, blk, 0, s, gy, xi, yi, gamma, mean, rstd, gx, part, rows, slope); break;
     }
-    hipLaunchKernelGGL(ln_lrelu_finish_kernel, dim3((unsigned)(2 * D / 64)), dim3(1024), 0, s, part, blocks, D, grad_gamma, grad_beta);
+    hipLaunchKernelGGL(ln_lrelu_finish_kernel, dim3((unsigned)(3 * D / 64)), dim3(1024), 0, s, part, blocks, D, grad_gamma, grad_beta, grad_xsum);
     return (int)hipGetLastError();
 }
 
@@ -445,10 +451,10 @@ extern "C" int ddsp_ln_lrelu_forward(const float *x, const float *gamma, const f
 }
 
 extern "C" int ddsp_ln_lrelu_backward(const float *grad_y, const float *x, const float *y, const float *gamma, const float *mean,
-                                      const float *rstd, float *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
+                                      const float *rstd, float *grad_x, float *grad_gamma, float *grad_beta, float *grad_xsum, void *scratch,
                                       long rows, int D, float slope, void *stream)
 {
-    return ln_backward<IoF32>(grad_y, x, y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, scratch, rows, D, slope, (hipStream_t)stream);
+    return ln_backward<IoF32>(grad_y, x, y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, grad_xsum, scratch, rows, D, slope, (hipStream_t)stream);
 }
 
 extern "C" int ddsp_ln_lrelu_forward_16(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd,
@@ -460,12 +466,12 @@ extern "C" int ddsp_ln_lrelu_forward_16(const void *x, const float *gamma, const
 }
 
 extern "C" int ddsp_ln_lrelu_backward_16(const void *grad_y, const void *x, const void *y, const float *gamma, const float *mean,
-                                         const float *rstd, void *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
+                                         const float *rstd, void *grad_x, float *grad_gamma, float *grad_beta, float *grad_xsum, void *scratch,
                                          long rows, int D, float slope, int io_type, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    if (io_type == DDSP_IO_BF16) return ln_backward<IoBf16>(grad_y, x, y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, scratch, rows, D, slope, s);
-    if (io_type == DDSP_IO_F16) return ln_backward<IoF16>(grad_y, x, y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, scratch, rows, D, slope, s);
+    if (io_type == DDSP_IO_BF16) return ln_backward<IoBf16>(grad_y, x, y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, grad_xsum, scratch, rows, D, slope, s);
+    if (io_type == DDSP_IO_F16) return ln_backward<IoF16>(grad_y, x, y, gamma, mean, rstd, grad_x, grad_gamma, grad_beta, grad_xsum, scratch, rows, D, slope, s);
     return DDSP_EINVAL;
 }
 

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _lib
 from . import dense
@@ -31,34 +32,63 @@ def _dense_stack(n_in: int, width: int, depth: int) -> nn.Module:
     return stack
 
 
+_LN_IO = {torch.bfloat16: 1, torch.float16: 2}
+
+
+def _ln_forward(x, g, b, eps, slope):
+    """x [.., D] contiguous (fp32 / bf16 / fp16), g / b fp32 -> (y like x, mean, rstd): include/ddsp_hip.h ddsp_ln_lrelu_forward*."""
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    L = _lib.lib()
+    with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        if x.dtype == torch.float32:
+            rc = L.ddsp_ln_lrelu_forward(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                         rows, D, float(eps), float(slope), stream)
+        else:
+            rc = L.ddsp_ln_lrelu_forward_16(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                            rows, D, float(eps), float(slope), _LN_IO[x.dtype], stream)
+    _lib.check(rc, "ddsp_ln_lrelu_forward")
+    return y, mean, rstd
+
+
+def _ln_backward(gy, x, y, g, mean, rstd, slope, want_xsum):
+    """-> (grad_x like x, d gamma, d beta, column sums of grad_x or None), parameter gradients fp32."""
+    D = x.shape[-1]
+    rows = x.numel() // D
+    gy = gy.contiguous().to(x.dtype)
+    gx = torch.empty_like(x)
+    out = torch.empty((3, D), device=x.device, dtype=torch.float32)
+    xsum = out[2] if want_xsum else None
+    L = _lib.lib()
+    scratch = torch.empty(L.ddsp_ln_lrelu_scratch_bytes(D), device=x.device, dtype=torch.uint8)
+    with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        args = (gy.data_ptr(), x.data_ptr(), y.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gx.data_ptr(), out[0].data_ptr(),
+                out[1].data_ptr(), None if xsum is None else xsum.data_ptr(), scratch.data_ptr(), rows, D, float(slope))
+        if x.dtype == torch.float32:
+            rc = L.ddsp_ln_lrelu_backward(*args, stream)
+        else:
+            rc = L.ddsp_ln_lrelu_backward_16(*args, _LN_IO[x.dtype], stream)
+    _lib.check(rc, "ddsp_ln_lrelu_backward")
+    return gx, out[0], out[1], xsum
+
+
 class _LayerNormLeakyReLU(torch.autograd.Function):
     """LayerNorm -> LeakyReLU of one MLP block as one HIP pass each way (include/ddsp_hip.h: ddsp_ln_lrelu_*).
     fp32 activations take the fp32 entry points; bf16 / fp16 activations (torch.autocast: the Linear in front produced them
     and the Linear behind wants them) are read and written as such by the `_16` entry points -- no cast pass either side;
     statistics, gamma / beta and their gradients are fp32 in both cases."""
 
-    _IO = {torch.bfloat16: 1, torch.float16: 2}
-
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
     def forward(ctx, x, gamma, beta, eps, slope):
         x = x.contiguous()
-        D = x.shape[-1]
-        rows = x.numel() // D
         g, b = gamma.detach().contiguous().float(), beta.detach().contiguous().float()
-        y = torch.empty_like(x)
-        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
-        rstd = torch.empty_like(mean)
-        L = _lib.lib()
-        with torch.cuda.device(x.device):
-            stream = torch.cuda.current_stream().cuda_stream
-            if x.dtype == torch.float32:
-                rc = L.ddsp_ln_lrelu_forward(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                             rows, D, float(eps), float(slope), stream)
-            else:
-                rc = L.ddsp_ln_lrelu_forward_16(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                                rows, D, float(eps), float(slope), _LayerNormLeakyReLU._IO[x.dtype], stream)
-        _lib.check(rc, "ddsp_ln_lrelu_forward")
+        y, mean, rstd = _ln_forward(x, g, b, eps, slope)
         ctx.save_for_backward(x, y, g, mean, rstd)
         ctx.slope = float(slope)
         ctx.param_dtypes = (gamma.dtype, beta.dtype)
@@ -68,24 +98,43 @@ class _LayerNormLeakyReLU(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gy):
         x, y, g, mean, rstd = ctx.saved_tensors
-        D = x.shape[-1]
-        rows = x.numel() // D
-        gy = gy.contiguous().to(x.dtype)
-        gx = torch.empty_like(x)
-        dg, db = torch.empty_like(g), torch.empty_like(g)
-        L = _lib.lib()
-        scratch = torch.empty(L.ddsp_ln_lrelu_scratch_bytes(D), device=x.device, dtype=torch.uint8)
-        with torch.cuda.device(x.device):
-            stream = torch.cuda.current_stream().cuda_stream
-            if x.dtype == torch.float32:
-                rc = L.ddsp_ln_lrelu_backward(gy.data_ptr(), x.data_ptr(), y.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                              gx.data_ptr(), dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), rows, D, ctx.slope, stream)
-            else:
-                rc = L.ddsp_ln_lrelu_backward_16(gy.data_ptr(), x.data_ptr(), y.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                                 gx.data_ptr(), dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), rows, D, ctx.slope,
-                                                 _LayerNormLeakyReLU._IO[x.dtype], stream)
-        _lib.check(rc, "ddsp_ln_lrelu_backward")
+        gx, dg, db, _ = _ln_backward(gy, x, y, g, mean, rstd, ctx.slope, False)
         return gx, dg.to(ctx.param_dtypes[0]), db.to(ctx.param_dtypes[1]), None, None
+
+
+class _LinearBlock(torch.autograd.Function):
+    """Linear -> LayerNorm -> LeakyReLU of one MLP block (decoder.py:9-39) as ONE autograd node: the library GEMMs of dense._Linear
+    around the fused LayerNorm pass, whose backward also returns the column sums of its input gradient -- the Linear's bias
+    gradient, which therefore costs no pass (dense.colsum: two launches per layer) of its own."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, eps, slope):
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        if dt not in (torch.float32, torch.bfloat16, torch.float16):
+            dt = torch.float32
+        xc, wc = x.to(dt), dense._cast(weight, dt)
+        with torch.autocast("cuda", enabled=False):
+            h = F.linear(xc, wc, dense._cast(bias, dt)).contiguous()
+        g, b = gamma.detach().contiguous().float(), beta.detach().contiguous().float()
+        y, mean, rstd = _ln_forward(h, g, b, eps, slope)
+        ctx.save_for_backward(xc, wc, h, y, g, mean, rstd)
+        ctx.slope = float(slope)
+        ctx.meta = (x.dtype, weight.dtype, bias.dtype, gamma.dtype, beta.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, wc, h, y, g, mean, rstd = ctx.saved_tensors
+        xdt, wdt, cdt, gdt, bdt = ctx.meta
+        gh, dg, db, xsum = _ln_backward(gy, h, y, g, mean, rstd, ctx.slope, ctx.needs_input_grad[2])
+        gx = gw = None
+        with torch.autocast("cuda", enabled=False):
+            g2 = gh.reshape(-1, gh.shape[-1])
+            if ctx.needs_input_grad[0]:
+                gx = (g2 @ wc).view(xc.shape).to(xdt)
+            if ctx.needs_input_grad[1]:
+                gw = dense.weight_grad(g2, xc.reshape(-1, xc.shape[-1])).to(wdt)
+        return gx, gw, (None if xsum is None else xsum.to(cdt)), dg.to(gdt), db.to(bdt), None, None
 
 
 class _FirstBlock(torch.autograd.Function):
@@ -158,6 +207,12 @@ def _run_stack(stack: nn.Module, x: torch.Tensor) -> torch.Tensor:
             # x * w^T + b as one fp32 elementwise pass, also under autocast
             x = torch.addcmul(linear.bias.float(), x.float(), linear.weight.float().view(-1))
         else:
+            D = linear.out_features
+            if (x.is_cuda and x.dtype in _FUSED_DTYPES and torch.is_grad_enabled() and linear.bias is not None and linear.in_features >= 16
+                    and D % 256 == 0 and D <= 1024 and norm.elementwise_affine and norm.bias is not None and act.negative_slope > 0
+                    and (linear.weight.requires_grad or x.requires_grad)):
+                x = _LinearBlock.apply(x, linear.weight, linear.bias, norm.weight, norm.bias, norm.eps, act.negative_slope)
+                continue
             x = dense.linear(x, linear.weight, linear.bias)
         D = x.shape[-1]
         if (x.is_cuda and x.dtype in _FUSED_DTYPES and D % 256 == 0 and D <= 1024 and norm.elementwise_affine

@@ -282,14 +282,15 @@ int ddsp_scaled_sigmoid_backward(const float *x, const float *grad_y, float *gra
 /*
  * LayerNorm followed by LeakyReLU over rows of D = 256, 512, 768 or 1024 fp32 elements (the MLP blocks of
  * model/autoencoder/decoder.py:9-39 after their Linear): y = lrelu(gamma * (x - mean) * rstd + beta); the forward keeps
- * mean / rstd per row for the backward, which returns grad_x and (deterministically summed) grad_gamma / grad_beta.
- * scratch >= ddsp_ln_lrelu_scratch_bytes(D).
+ * mean / rstd per row for the backward, which returns grad_x and (deterministically summed) grad_gamma / grad_beta -- and, when
+ * grad_xsum is not null (ABI 3), the column sums of grad_x [D]: the bias gradient of the Linear in front of the block, which then
+ * needs no pass of its own.  scratch >= ddsp_ln_lrelu_scratch_bytes(D).
  */
 size_t ddsp_ln_lrelu_scratch_bytes(int D);
 int ddsp_ln_lrelu_forward(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd,
                           long rows, int D, float eps, float slope, void *stream);
 int ddsp_ln_lrelu_backward(const float *grad_y, const float *x, const float *y, const float *gamma, const float *mean,
-                           const float *rstd, float *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
+                           const float *rstd, float *grad_x, float *grad_gamma, float *grad_beta, float *grad_xsum, void *scratch,
                            long rows, int D, float slope, void *stream);
 /* The same passes on 16-bit activations (io_type: DDSP_IO_BF16 / DDSP_IO_F16) for torch.autocast callers: x, y and their
  * gradients are bf16 / fp16 arrays (read and written as such: no cast pass on either side), gamma / beta, the row
@@ -299,7 +300,7 @@ int ddsp_ln_lrelu_backward(const float *grad_y, const float *x, const float *y, 
 int ddsp_ln_lrelu_forward_16(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd,
                              long rows, int D, float eps, float slope, int io_type, void *stream);
 int ddsp_ln_lrelu_backward_16(const void *grad_y, const void *x, const void *y, const float *gamma, const float *mean,
-                              const float *rstd, void *grad_x, float *grad_gamma, float *grad_beta, void *scratch,
+                              const float *rstd, void *grad_x, float *grad_gamma, float *grad_beta, float *grad_xsum, void *scratch,
                               long rows, int D, float slope, int io_type, void *stream);
 
 

@@ -58,7 +58,7 @@ def test_argument_validation_without_gpu():
     assert L.ddsp_scaled_sigmoid_forward(None, None, 10, None) == -1 and L.ddsp_scaled_sigmoid_forward(None, None, 0, None) == 0
     assert L.ddsp_ln_lrelu_forward(None, None, None, None, None, None, 4, 512, 1e-5, 0.01, None) == -1
     assert L.ddsp_ln_lrelu_scratch_bytes(512) > 0
-    assert L.ddsp_ln_lrelu_backward(None, None, None, None, None, None, None, None, None, None, 0, 512, 0.01, None) == -1   # empty rows still need dgamma/dbeta
+    assert L.ddsp_ln_lrelu_backward(None, None, None, None, None, None, None, None, None, None, None, 0, 512, 0.01, None) == -1   # empty rows still need dgamma/dbeta
     assert L.ddsp_gru_set_fault_step(-1) == -2 and L.ddsp_gru_set_fault_step(0) == 0
     # round-2 entry points: framing, one-kernel loss scale, column sums, reverb, counter-driven noise backward
     assert L.ddsp_stft_frames(None, None, None, 1, 4096, 512, 128, None) == -1 and L.ddsp_stft_frames(None, None, None, 0, 4096, 512, 128, None) == 0
