@@ -84,7 +84,7 @@ def lib():
     L.ddsp_gru_forward_bf16.restype = i32
     L.ddsp_gru_forward_bf16.argtypes = [vp] * 9 + [i32] * 3 + [vp]
     L.ddsp_gru_backward_bf16.restype = i32
-    L.ddsp_gru_backward_bf16.argtypes = [vp] * 11 + [i32] * 3 + [vp]
+    L.ddsp_gru_backward_bf16.argtypes = [vp] * 11 + [i32] * 4 + [vp]
     L.ddsp_gru_set_mode.restype = i32
     L.ddsp_gru_set_mode.argtypes = [i32]
     L.ddsp_gru_set_fault_step.restype = i32

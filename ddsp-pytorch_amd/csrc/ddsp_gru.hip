@@ -67,6 +67,7 @@ struct GruParams {
     int B, T, Hd;
     int NG, NGpad, NW, BL;  // groups, padded group count (blockIdx modulus), workgroups per group, rows per group
     int lowp;             // 1: the products run on the matrix cores in bf16 (autocast callers), fp32 accumulate
+    int io16;             // with lowp, backward: d_gi / d_gh are bf16 arrays -- what the autocast GEMMs behind the recurrence consume
     long spin_ticks;      // bound of every spin, in ticks of the 100 MHz wall clock
     int fault_step;       // test hook (ddsp_gru_set_mode(2)): workgroup 0 withholds its publishes from this step on; -1 = off
 };
@@ -598,6 +599,15 @@ __device__ __forceinline__ bf16x8_t to_bf16x8(float4 a, float4 b)
     return r;
 }
 
+// d_gi / d_gh as the caller's GEMMs want them (GruParams::io16): bf16 arrays behind the float pointers, or fp32.
+// (The forward's gi stays fp32: read as bf16 -- even with the conversion deferred to the step that uses the value -- the forward
+//  kernel measured 0.87 -> 1.05 ms at the training shape; the cast pass in front of it costs 0.02 ms.)
+__device__ __forceinline__ void store_gate_grad(const GruParams &p, float *base, size_t i, float v)
+{
+    if (p.io16) reinterpret_cast<__bf16 *>(base)[i] = (__bf16)v;
+    else base[i] = v;
+}
+
 constexpr int kMfmaRows = 16;     // rows of one MFMA tile = the most batch rows a group may hold in these variants
 
 // Forward: the tile is turned round -- M = (unit, gate) packed four to a unit (r, z, n, pad), N = the group's rows -- so that one
@@ -823,12 +833,12 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_mfma_kernel(GruParams p)
             const float dr_pre = dh * f_r, dz_pre = dh * f_z, dhn = dh * f_hn, dn_pre = dh * f_n;
             direct = dh * f_dir;
             if (s < fault_from) publish3(slot + (size_t)gr * HP + gk, epoch, dr_pre, dz_pre, dhn);
-            p.d_gi[bt * G3 + gk] = dr_pre;
-            p.d_gi[bt * G3 + Hd + gk] = dz_pre;
-            p.d_gi[bt * G3 + 2 * Hd + gk] = dn_pre;
-            p.d_gh[bt * G3 + gk] = dr_pre;
-            p.d_gh[bt * G3 + Hd + gk] = dz_pre;
-            p.d_gh[bt * G3 + 2 * Hd + gk] = dhn;
+            store_gate_grad(p, p.d_gi, bt * G3 + gk, dr_pre);
+            store_gate_grad(p, p.d_gi, bt * G3 + Hd + gk, dz_pre);
+            store_gate_grad(p, p.d_gi, bt * G3 + 2 * Hd + gk, dn_pre);
+            store_gate_grad(p, p.d_gh, bt * G3 + gk, dr_pre);
+            store_gate_grad(p, p.d_gh, bt * G3 + Hd + gk, dz_pre);
+            store_gate_grad(p, p.d_gh, bt * G3 + 2 * Hd + gk, dhn);
         }
         s_reached = s + 1;
         // 2. the group's gate gradients -> LDS (3 * nrows rows of width Hd)
@@ -865,8 +875,8 @@ __global__ void __launch_bounds__(256, 1) gru_bwd_mfma_kernel(GruParams p)
                 const size_t bt = (size_t)(row0 + gr) * p.T + (p.T - 1 - s);
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
-                    p.d_gi[bt * G3 + g * Hd + gk] = nan;
-                    p.d_gh[bt * G3 + g * Hd + gk] = nan;
+                    store_gate_grad(p, p.d_gi, bt * G3 + g * Hd + gk, nan);
+                    store_gate_grad(p, p.d_gh, bt * G3 + g * Hd + gk, nan);
                 }
             }
         }
@@ -1067,6 +1077,7 @@ int run_gru(GruParams &p, void *scratch, bool backward, hipStream_t s)
     // is at least as accurate, is taken there.
     // (the backward's packed granules carry 16-bit epochs: sequences of 65 536 steps and more take the fp32 kernels)
     const bool use_mfma = p.lowp && (backward ? p.T < 65536 : pl.BL >= 2);
+    if (p.io16 && !use_mfma) return DDSP_ERANGE;      // (the fp32 kernels write fp32 arrays only)
     if (use_mfma) {
         switch (pl.KP) {
             case 4: e = launch_mfma<4>(p, backward, s); break;
@@ -1154,15 +1165,17 @@ extern "C" int ddsp_gru_forward_bf16(const float *gi, const float *w_hh, const f
 }
 
 extern "C" int ddsp_gru_backward_bf16(const float *dy, const float *dhT, const float *w_hh, const float *h0, const float *y,
-                                      const float *gates, const float *hn, float *d_gi, float *d_gh, float *dh0, void *scratch,
-                                      int B, int T, int Hd, void *stream)
+                                      const float *gates, const float *hn, void *d_gi, void *d_gh, float *dh0, void *scratch,
+                                      int B, int T, int Hd, int io_type, void *stream)
 {
     if (B == 0) return 0;
     if (!dy || !w_hh || !y || !gates || !hn || !d_gi || !d_gh || !dh0 || !scratch || B < 0 || T <= 0 || Hd <= 0) return DDSP_EINVAL;
+    if (io_type != 0 && io_type != DDSP_IO_BF16) return DDSP_EINVAL;
     GruParams p = {};
+    p.io16 = io_type == DDSP_IO_BF16;
     p.dy = dy; p.dhT = dhT; p.w_hh = w_hh; p.h0 = h0; p.y = const_cast<float *>(y);
     p.gates = const_cast<float *>(gates); p.hn = const_cast<float *>(hn);
-    p.d_gi = d_gi; p.d_gh = d_gh; p.dh0 = dh0;
+    p.d_gi = (float *)d_gi; p.d_gh = (float *)d_gh; p.dh0 = dh0;
     p.B = B; p.T = T; p.Hd = Hd; p.lowp = 1;
     return run_gru(p, scratch, true, (hipStream_t)stream);
 }

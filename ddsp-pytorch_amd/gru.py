@@ -84,12 +84,14 @@ def gru_forward(gi, w_hh, b_hh, h0, save: bool, scratch_out: list | None = None,
     return y, hT, gates, hn
 
 
-def gru_backward(dy, dhT, w_hh, h0, y, gates, hn, scratch_out: list | None = None, lowp: bool = False):
-    """Raw launcher of ddsp_gru_backward -> (d_gi [B,T,3Hd], d_gh [B,T,3Hd], dh0 [B,Hd])."""
+def gru_backward(dy, dhT, w_hh, h0, y, gates, hn, scratch_out: list | None = None, lowp: bool = False, io16: bool = False):
+    """Raw launcher of ddsp_gru_backward -> (d_gi [B,T,3Hd], d_gh [B,T,3Hd], dh0 [B,Hd]).
+    `io16` (with `lowp`): d_gi / d_gh come back as bf16 tensors, ready for the autocast GEMMs that consume them."""
     B, T, Hd = y.shape
     L = _lib.lib()
-    d_gi = torch.empty_like(gates)
-    d_gh = torch.empty_like(gates)
+    io16 = io16 and lowp
+    d_gi = torch.empty_like(gates, dtype=torch.bfloat16 if io16 else torch.float32)
+    d_gh = torch.empty_like(d_gi)
     dh0 = torch.empty((B, Hd), device=y.device, dtype=torch.float32)
     with torch.cuda.device(y.device):
         cap = L.ddsp_gru_max_batch(Hd, 3 if lowp else 1)
@@ -98,10 +100,11 @@ def gru_backward(dy, dhT, w_hh, h0, y, gates, hn, scratch_out: list | None = Non
         for lo in range(0, B, cap):
             hi = min(B, lo + cap)
             scratch = torch.empty(L.ddsp_gru_scratch_bytes(hi - lo, Hd), device=y.device, dtype=torch.uint8)
-            rc = launch(dy[lo:hi].data_ptr(), _ptr(dhT[lo:hi]) if dhT is not None else None, w_hh.data_ptr(),
-                                     _ptr(h0[lo:hi]) if h0 is not None else None, y[lo:hi].data_ptr(), gates[lo:hi].data_ptr(),
-                                     hn[lo:hi].data_ptr(), d_gi[lo:hi].data_ptr(), d_gh[lo:hi].data_ptr(), dh0[lo:hi].data_ptr(),
-                                     scratch.data_ptr(), hi - lo, T, Hd, stream)
+            args = (dy[lo:hi].data_ptr(), _ptr(dhT[lo:hi]) if dhT is not None else None, w_hh.data_ptr(),
+                    _ptr(h0[lo:hi]) if h0 is not None else None, y[lo:hi].data_ptr(), gates[lo:hi].data_ptr(),
+                    hn[lo:hi].data_ptr(), d_gi[lo:hi].data_ptr(), d_gh[lo:hi].data_ptr(), dh0[lo:hi].data_ptr(),
+                    scratch.data_ptr(), hi - lo, T, Hd)
+            rc = launch(*args, 1 if io16 else 0, stream) if lowp else launch(*args, stream)
             _lib.check(rc, "ddsp_gru_backward")
             if scratch_out is not None:
                 scratch_out.append(scratch)
@@ -116,16 +119,22 @@ def gru_status(scratch) -> int:
 
 
 class _Recurrence(torch.autograd.Function):
+    """gi [B,T,3Hd] -> (y, h_T).  Everything at the boundary is fp32, with one exception: under bf16 autocast the input projection
+    wants a bf16 gradient back and the W_hh gradient GEMM consumes bf16 too -- the backward kernel writes d_gi / d_gh as bf16
+    (include/ddsp_hip.h: io_type) instead of a cast pass on each.  (`gi` itself is cast to fp32 in front of the forward kernel:
+    reading it as bf16 measured slower than the cast costs.)"""
+
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, gi, w_hh, b_hh, h0, gemm_dtype=None):
+        lowp = gemm_dtype is not None        # under autocast the recurrence's products run on the matrix cores in bf16 as well
+        io16 = lowp and gi.dtype == torch.bfloat16
+        gi_dtype = gi.dtype
         gi = gi.contiguous().float()
         w = w_hh.detach().contiguous().float()
         b = None if b_hh is None else b_hh.detach().contiguous().float()
         h = None if h0 is None else h0.detach().contiguous().float()
         need = any(ctx.needs_input_grad)
         launched = [] if _debug else None
-        lowp = gemm_dtype is not None        # under autocast the recurrence's products run on the matrix cores in bf16 as well
         y, hT, gates, hn = gru_forward(gi.detach(), w, b, h, save=need, scratch_out=launched, lowp=lowp)
         if _debug:
             _raise_on_timeout(launched, "ddsp_gru_forward")
@@ -133,30 +142,33 @@ class _Recurrence(torch.autograd.Function):
             ctx.save_for_backward(w, h, y, gates, hn)
             ctx.has_bias = b is not None
             ctx.gemm_dtype = gemm_dtype
+            ctx.io16 = io16
+            ctx.in_dtypes = (w_hh.dtype, None if b_hh is None else b_hh.dtype, None if h0 is None else h0.dtype, gi_dtype)
         return y, hT
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy, dhT):
         w, h0, y, gates, hn = ctx.saved_tensors
         B, T, Hd = y.shape
         dy = torch.zeros_like(y) if dy is None else dy.contiguous().float()
         dhT = None if dhT is None else dhT.contiguous().float()
         launched = [] if _debug else None
-        d_gi, d_gh, dh0 = gru_backward(dy, dhT, w, h0, y, gates, hn, scratch_out=launched, lowp=ctx.gemm_dtype is not None)
+        d_gi, d_gh, dh0 = gru_backward(dy, dhT, w, h0, y, gates, hn, scratch_out=launched, lowp=ctx.gemm_dtype is not None, io16=ctx.io16)
         if _debug:
             _raise_on_timeout(launched, "ddsp_gru_backward")
         dw = db = None
-        if ctx.needs_input_grad[1]:
-            first = h0 if h0 is not None else torch.zeros((B, Hd), device=y.device, dtype=y.dtype)
-            h_prev = torch.cat((first.unsqueeze(1), y[:, :-1]), dim=1)          # h_{t-1} for every step
-            a, b_ = d_gh.reshape(B * T, 3 * Hd), h_prev.reshape(B * T, Hd)
-            if ctx.gemm_dtype is not None:                                      # the forward ran under autocast: so does this GEMM
-                a, b_ = a.to(ctx.gemm_dtype), b_.to(ctx.gemm_dtype)
-            dw = dense.weight_grad(a, b_)                                       # library GEMMs [3Hd, BT] x [BT, Hd], split over BT
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dense.colsum(d_gh.reshape(B * T, 3 * Hd))
-        return d_gi, dw, db, (dh0 if ctx.needs_input_grad[3] else None), None
+        wdt, bdt, hdt, gdt = ctx.in_dtypes
+        with torch.autocast("cuda", enabled=False):
+            if ctx.needs_input_grad[1]:
+                first = h0 if h0 is not None else torch.zeros((B, Hd), device=y.device, dtype=y.dtype)
+                h_prev = torch.cat((first.unsqueeze(1), y[:, :-1]), dim=1)          # h_{t-1} for every step
+                a, b_ = d_gh.reshape(B * T, 3 * Hd), h_prev.reshape(B * T, Hd)
+                if ctx.gemm_dtype is not None:                                      # the forward ran under autocast: so does this GEMM
+                    a, b_ = a.to(ctx.gemm_dtype), b_.to(ctx.gemm_dtype)
+                dw = dense.weight_grad(a, b_).to(wdt)                               # library GEMMs [3Hd, BT] x [BT, Hd], split over BT
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = dense.colsum(d_gh.reshape(B * T, 3 * Hd)).to(bdt)
+        return d_gi.to(gdt), dw, db, (dh0.to(hdt) if ctx.needs_input_grad[3] else None), None
 
 
 class GRU(nn.GRU):

@@ -166,12 +166,14 @@ int ddsp_gru_status(const void *scratch, int *status_host);
 /* The same recurrences for torch.autocast callers (train/train.py:50 `precision=16`): the products h W_hh^T (forward) and
  * (dr, dz, dhn) W_hh (backward) run on the matrix cores in bf16 with fp32 accumulation (v_mfma_f32_16x16x32_bf16), every
  * tensor at the boundary, the gate arithmetic and the hand-off stay fp32.  At most 16 rows per group: ddsp_gru_max_batch(Hd, 2)
- * rows per launch.  Results differ from the fp32 entry points at bf16 precision (~1e-3). */
+ * rows per launch.  Results differ from the fp32 entry points at bf16 precision (~1e-3).
+ * Backward io_type (ABI 3): 0 = fp32 arrays as above; DDSP_IO_BF16 (= 1) = `d_gi` / `d_gh` are written as bf16 arrays -- what the
+ * autocast GEMMs behind the recurrence consume, so that no cast pass runs on them. */
 int ddsp_gru_forward_bf16(const float *gi, const float *w_hh, const float *b_hh, const float *h0, float *y, float *hT,
                           float *gates, float *hn, void *scratch, int B, int T, int Hd, void *stream);
 int ddsp_gru_backward_bf16(const float *dy, const float *dhT, const float *w_hh, const float *h0, const float *y,
-                           const float *gates, const float *hn, float *d_gi, float *d_gh, float *dh0, void *scratch,
-                           int B, int T, int Hd, void *stream);
+                           const float *gates, const float *hn, void *d_gi, void *d_gh, float *dh0, void *scratch,
+                           int B, int T, int Hd, int io_type, void *stream);
 /* Test hooks (process-global bit mask; 0 restores the default).  Bit 0: deal every group's workgroups over all XCDs (odd
  * blockIdx modulus) instead of keeping a group on one XCD -- bitwise the same results either way (placement only changes
  * speed).  Bit 1: fault injection -- workgroup 0 withholds its publishes from step ddsp_gru_set_fault_step() on and the
