@@ -295,9 +295,13 @@ def main():
     # libraries print to stdout on their own (gloo's "[Gloo] Rank 0 is connected ..." at the first collective): from here on
     # fd 1 is stderr for everybody, and only the result line goes to the real stdout
     global RESULT
-    sys.stdout.flush()
-    RESULT = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
+    try:
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        RESULT = os.fdopen(saved, "w")
+    except OSError:          # no usable stderr / stdout descriptors: leave stdout alone
+        RESULT = sys.stdout
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
