@@ -11,7 +11,7 @@ import subprocess
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("DDSP_HIP_LIB", os.path.join(_DIR, "libddsp_hip.so"))  # override: A/B builds (tools/ab_bench.sh)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -53,6 +53,10 @@ def lib():
     L.ddsp_osc_scratch_bytes.argtypes = [i32, i32, i32]
     L.ddsp_osc_forward.restype = i32
     L.ddsp_osc_forward.argtypes = [vp] * 8 + [i32] * 5 + [vp]
+    L.ddsp_osc_forward_ex.restype = i32
+    L.ddsp_osc_forward_ex.argtypes = [vp] * 8 + [i32] * 5 + [ctypes.c_uint, vp]
+    L.ddsp_osc_set_path.restype = i32
+    L.ddsp_osc_set_path.argtypes = [i32]
     L.ddsp_noise_forward.restype = i32
     L.ddsp_noise_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, u64, u64, i32, vp]
     L.ddsp_noise_forward_counter.restype = i32
@@ -145,7 +149,7 @@ def lib():
     return L
 
 
-EXPORTS = ("ddsp_hip_abi_version", "ddsp_test_hooks_enabled", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_noise_forward", "ddsp_noise_forward_counter",
+EXPORTS = ("ddsp_hip_abi_version", "ddsp_test_hooks_enabled", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_osc_forward_ex", "ddsp_osc_set_path", "ddsp_noise_forward", "ddsp_noise_forward_counter",
            "ddsp_osc_backward_scratch_bytes", "ddsp_osc_backward", "ddsp_noise_backward", "ddsp_noise_backward_counter",
            "ddsp_osc_set_tiling", "ddsp_noise_set_generic", "ddsp_profile_enable", "ddsp_profile_read",
            "ddsp_gru_scratch_bytes", "ddsp_gru_max_batch", "ddsp_gru_forward", "ddsp_gru_backward", "ddsp_gru_forward_bf16", "ddsp_gru_backward_bf16", "ddsp_gru_status", "ddsp_gru_set_mode", "ddsp_gru_set_fault_step",

@@ -378,6 +378,7 @@ __global__ void __launch_bounds__(256) osc_totals_kernel(OscParams p)
 __global__ void __launch_bounds__(256) osc_supscan_kernel(OscParams p)
 {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx == 0) p.redo_flag[2] = kFrameScratchTag;   // this scratch can serve ddsp_osc_backward
     if (idx >= (long)p.B * p.H) return;
     const int b = (int)(idx / p.H), h = (int)(idx - (long)b * p.H);
     double *col = p.sup + (long)b * p.NSB * p.H + h;
@@ -566,6 +567,7 @@ double tiling_cost(int H, int K, int logG, long frames)
 }
 
 std::atomic<int> g_forced_k{0};  // ddsp_osc_set_tiling: 0 = automatic (a test / tuning hook; read once per launch)
+std::atomic<int> g_path{0};      // ddsp_osc_set_path: 0 = automatic, 1 = frame kernels only
 
 bool pick_tiling(int H, long frames, Tiling *out)
 {
@@ -626,16 +628,33 @@ extern "C" int ddsp_osc_set_tiling(int harmonics_per_lane)
     return 0;
 }
 
+extern "C" int ddsp_osc_set_path(int path)
+{
+    if (path != 0 && !ddsp_hooks_on()) return DDSP_EPERM;
+    if (path < 0 || path > 1) return DDSP_ERANGE;
+    g_path.store(path, std::memory_order_relaxed);
+    return 0;
+}
+
 extern "C" size_t ddsp_osc_scratch_bytes(int B, int T, int H)
 {
     if (B <= 0 || T <= 0 || H <= 0) return 0;
     const size_t n = (size_t)B * T * H;
-    return 2 * align256(n * sizeof(float)) + align256(n * sizeof(double)) + align256(sup_elems(B, T, H) * sizeof(double)) + 256;
+    const size_t frame = 2 * align256(n * sizeof(float)) + align256(n * sizeof(double)) + align256(sup_elems(B, T, H) * sizeof(double)) + 256;
+    const size_t chunk = chunk_scratch_bytes(B, T, H);
+    return frame > chunk ? frame : chunk;
 }
 
 extern "C" int ddsp_osc_forward(const float *f0, const float *c, const float *a, float *y, void *scratch,
                                 const float *live_in, float *live_out, float *dbg_phi, int B, int T, int H, int hop,
                                 int sample_rate, void *stream)
+{
+    return ddsp_osc_forward_ex(f0, c, a, y, scratch, live_in, live_out, dbg_phi, B, T, H, hop, sample_rate, 0u, stream);
+}
+
+extern "C" int ddsp_osc_forward_ex(const float *f0, const float *c, const float *a, float *y, void *scratch,
+                                   const float *live_in, float *live_out, float *dbg_phi, int B, int T, int H, int hop,
+                                   int sample_rate, unsigned flags, void *stream)
 {
     if (B == 0) return 0;
     if (!f0 || !c || !a || !y || !scratch || B < 0 || T <= 0 || H <= 0 || hop <= 0 || sample_rate <= 0) return DDSP_EINVAL;
@@ -650,6 +669,8 @@ extern "C" int ddsp_osc_forward(const float *f0, const float *c, const float *a,
 
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipSuccess;
+    if (!(flags & DDSP_OSC_KEEP_FRAME_SCRATCH) && g_path.load(std::memory_order_relaxed) == 0 && chunked_eligible(p))
+        return (int)launch_chunked_k(p, scratch, s);
     switch (p.K) {
 #define DDSP_CASE(KK) case KK: e = launch_frames<KK>(p, s); break;
         DDSP_CASE(4) DDSP_CASE(8) DDSP_CASE(12) DDSP_CASE(13) DDSP_CASE(15) DDSP_CASE(16) DDSP_CASE(20) DDSP_CASE(23) DDSP_CASE(25)

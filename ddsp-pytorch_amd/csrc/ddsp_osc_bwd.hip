@@ -129,6 +129,7 @@ template <int K, bool POW2>
 __global__ void __launch_bounds__(256) osc_bwd_kernel(OscParams p, int use_lds)
 {
     extern __shared__ float g_s[];  // [FPB][R] tile of grad_y (when it fits)
+    if (p.redo_flag[2] != kFrameScratchTag) return;   // not a frame-form scratch: the finish kernel poisons the gradients
     const int G = 1 << p.logG, FPB = 256 >> p.logG;
     const unsigned blk = xcd_block(blockIdx.x, gridDim.x);
     const long gid = (long)blk * 256 + threadIdx.x;
@@ -223,6 +224,13 @@ __global__ void __launch_bounds__(256) osc_bwd_finish_kernel(OscParams p)
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (long)p.B * p.T) return;
+    if (p.redo_flag[2] != kFrameScratchTag) {
+        // the forward was not asked to keep the frame-form scratch (DDSP_OSC_KEEP_FRAME_SCRATCH): fail loudly
+        const float nan = __builtin_nanf("");
+        for (int h = lane; h < p.H; h += 64) p.grad_c[row * p.H + h] = nan;
+        if (lane == 0) p.grad_a[row] = nan;
+        return;
+    }
     const int b = (int)(row / p.T), t = (int)(row - (long)b * p.T);
     const long base = (long)b * p.T;
     // sources: slot 1 of frame t; slot 0 of frame t+1 (its row t+1-1); slot 2 of frame t-1; the clamped slots at the clip ends

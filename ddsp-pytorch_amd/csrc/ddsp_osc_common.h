@@ -12,6 +12,7 @@ constexpr float kInvTwoPi32 = 0.15915493667125702f; // fl32(1/fl32(2*pi))
 constexpr float kRevPerRad = 0.15915494309189535f;  // 1/(2*pi) for v_sin_f32 (argument in revolutions)
 constexpr float kFastPhaseLimit = 1.0e7f;           // fast modulo is exact while P/2pi32 < 2^21
 constexpr float kRoundMagic = 12582912.0f;          // 1.5*2^23: (x + magic) - magic = rint(x) for |x| < 2^22
+constexpr int kFrameScratchTag = 0x46524d45;        // flag word [2] of a scratch buffer the FRAME kernels filled (what the backward re-walks)
 
 struct OscParams {
     const float *f0, *c, *a;
@@ -34,6 +35,15 @@ struct OscParams {
     int force_exact;
     int stage_out;    // synth: stage 32 output samples per frame in LDS, store whole 128-byte lines (pow2 hop >= 64, G in 4..16)
     int pow2;         // hop is a power of two and the clip has <= 2^23 samples: incremental weights, uniform loops
+    // chunked form (ddsp_osc_chunk.hip): power-of-two hop >= 64, 4..16 lanes per row group
+    double *ctot;     // scratch [B,NC,H]: chunk totals, then (in place) their exclusive scan along the row
+    double *tot;      // scratch [B,T+1+NC,H]: totals of the pieces (segment s of chunk c at index s+c) that have silent slots
+    int *klive;       // scratch [RB*NC,P]: live-slot class of every piece of every wave task
+    int *redo;        // scratch [RB*NC]: wave tasks the fast synth kernel declined
+    int Lc, NC, RB;   // chunk length in samples, chunks per row, row blocks (64/G rows each)
+    int P;            // pieces per chunk (upper bound) = Lc/R + 2
+    int lgR;          // log2(R)
+    float inv2R;      // 1/(2R)
     float scale;      // fl32(1/R): F.interpolate's source-index scale
     float nyquist;    // float(sample_rate // 2)
     float sr;         // float(sample_rate)
@@ -161,5 +171,10 @@ inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 inline size_t sup_elems(int B, int T, int H) { return (size_t)B * ((size_t)(T + 3) / 4) * H; }
 // Fills the shape-derived fields and carves the scratch buffer; returns false if no tiling exists for H.
 bool setup_params(OscParams &p, void *scratch, int B, int T, int H, int hop, int sample_rate);
+// chunked form (ddsp_osc_chunk.hip)
+bool chunked_eligible(const OscParams &p);
+size_t chunk_scratch_bytes(int B, int T, int H);
+void pick_chunks(int T, int R, int RB, long slots, int *Lc_out, int *NC_out);
+hipError_t launch_chunked_k(const OscParams &p, void *scratch, hipStream_t s);
 
 }  // namespace ddsp_osc

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DDSP_HIP_ABI_VERSION 3
+#define DDSP_HIP_ABI_VERSION 4
 
 #define DDSP_EINVAL (-1)   /* null pointer / non-positive size */
 #define DDSP_ERANGE (-2)   /* shape outside what the kernels are built for */
@@ -66,6 +66,15 @@ size_t ddsp_osc_scratch_bytes(int B, int T, int H);
 int ddsp_osc_forward(const float *f0, const float *c, const float *a, float *y, void *scratch,
                      const float *live_in, float *live_out, float *dbg_phi,
                      int B, int T, int H, int hop, int sample_rate, void *stream);
+/*
+ * The same with flags.  DDSP_OSC_KEEP_FRAME_SCRATCH: the caller will hand `scratch` to ddsp_osc_backward, which re-walks
+ * the frame-rate layout (start phase of every frame); without it the forward is free to take the chunked form
+ * (power-of-two hops >= 64), whose scratch the backward refuses (it then returns NaN gradients).
+ */
+#define DDSP_OSC_KEEP_FRAME_SCRATCH 1u
+int ddsp_osc_forward_ex(const float *f0, const float *c, const float *a, float *y, void *scratch,
+                        const float *live_in, float *live_out, float *dbg_phi,
+                        int B, int T, int H, int hop, int sample_rate, unsigned flags, void *stream);
 
 /*
  * Filtered noise (filtered_noise.py:40-53).
@@ -113,6 +122,9 @@ int ddsp_noise_backward_counter(const float *grad_y, float *grad_H, int B, int T
  * thread-safe; results are identical for every setting.
  */
 int ddsp_osc_set_tiling(int harmonics_per_lane);
+/* Test / tuning hook: 1 = frame kernels for every shape (the round 1-3 decomposition, one lane group per frame), 0 = automatic
+ * (chunked form where it applies).  Same results within rounding. */
+int ddsp_osc_set_path(int path);
 
 /* Test / tuning hook (process-global, read once per launch): bit 0 forces the generic one-frame-per-workgroup noise kernels
  * (any hop) instead of the batched ones (hop % 8 == 0, tile fits LDS); bit 1 keeps the direct (time-domain) forms where the

@@ -45,7 +45,7 @@ def run_osc(g, debug=False, prefix=""):
 
 def test_native_library_is_loaded():
     L = ddsp._lib.lib()
-    assert L.ddsp_hip_abi_version() == 3
+    assert L.ddsp_hip_abi_version() == ddsp._lib.ABI_VERSION == 4
     with open("/proc/self/maps") as f:
         assert "libddsp_hip.so" in f.read()
 

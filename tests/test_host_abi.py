@@ -35,7 +35,7 @@ def test_header_symbols_exported():
 
 def test_abi_version_and_scratch_size():
     L = ddsp._lib.lib()
-    assert L.ddsp_hip_abi_version() == 3 == ddsp._lib.ABI_VERSION
+    assert L.ddsp_hip_abi_version() == 4 == ddsp._lib.ABI_VERSION
     assert L.ddsp_osc_scratch_bytes(0, 1, 1) == 0
     n = 64 * 500 * 100
     assert L.ddsp_osc_scratch_bytes(64, 500, 100) >= 16 * n
