@@ -57,6 +57,8 @@ def lib():
     L.ddsp_osc_forward_ex.argtypes = [vp] * 8 + [i32] * 5 + [ctypes.c_uint, vp]
     L.ddsp_osc_set_path.restype = i32
     L.ddsp_osc_set_path.argtypes = [i32]
+    L.ddsp_osc_plan.restype = i32
+    L.ddsp_osc_plan.argtypes = [i32] * 5 + [ctypes.POINTER(i32), i32]
     L.ddsp_noise_forward.restype = i32
     L.ddsp_noise_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, u64, u64, i32, vp]
     L.ddsp_noise_forward_counter.restype = i32
@@ -149,7 +151,7 @@ def lib():
     return L
 
 
-EXPORTS = ("ddsp_hip_abi_version", "ddsp_test_hooks_enabled", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_osc_forward_ex", "ddsp_osc_set_path", "ddsp_noise_forward", "ddsp_noise_forward_counter",
+EXPORTS = ("ddsp_hip_abi_version", "ddsp_test_hooks_enabled", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_osc_forward_ex", "ddsp_osc_set_path", "ddsp_osc_plan", "ddsp_noise_forward", "ddsp_noise_forward_counter",
            "ddsp_osc_backward_scratch_bytes", "ddsp_osc_backward", "ddsp_noise_backward", "ddsp_noise_backward_counter",
            "ddsp_osc_set_tiling", "ddsp_noise_set_generic", "ddsp_profile_enable", "ddsp_profile_read",
            "ddsp_gru_scratch_bytes", "ddsp_gru_max_batch", "ddsp_gru_forward", "ddsp_gru_backward", "ddsp_gru_forward_bf16", "ddsp_gru_backward_bf16", "ddsp_gru_status", "ddsp_gru_set_mode", "ddsp_gru_set_fault_step",
@@ -183,3 +185,12 @@ def check(rc: int, what: str) -> None:
     if rc == -3:
         raise DdspHipError(f"{what}: test / tuning hook refused (DDSP_EPERM): set DDSP_TEST_HOOKS=1 before the library is loaded")
     raise DdspHipError(f"{what}: HIP error {rc}")
+
+
+def osc_plan(B: int, T: int, H: int, hop: int, sample_rate: int) -> dict:
+    """What ddsp_osc_forward launches for this shape on the current device (include/ddsp_hip.h: ddsp_osc_plan)."""
+    out = (ctypes.c_int * 8)()
+    check(lib().ddsp_osc_plan(B, T, H, hop, sample_rate, out, 8), "ddsp_osc_plan")
+    keys = ("harmonics_per_lane", "lanes_per_row", "chunked", "chunk_samples", "chunks_per_row", "row_blocks",
+            "compute_units", "workgroups_per_unit")
+    return dict(zip(keys, list(out)))

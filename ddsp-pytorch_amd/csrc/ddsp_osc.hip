@@ -636,6 +636,24 @@ extern "C" int ddsp_osc_set_path(int path)
     return 0;
 }
 
+extern "C" int ddsp_osc_plan(int B, int T, int H, int hop, int sample_rate, int *out, int cap)
+{
+    if (!out || cap < 8 || B <= 0 || T <= 0 || H <= 0 || hop <= 0 || sample_rate <= 0) return DDSP_EINVAL;
+    OscParams p = {};
+    char dummy[1] = {};
+    if (!setup_params(p, dummy, B, T, H, hop, sample_rate)) return DDSP_ERANGE;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    out[0] = p.K;
+    out[1] = 1 << p.logG;
+    if (g_path.load(std::memory_order_relaxed) == 0 && chunked_eligible(p)) {
+        int cus = 0, wgs = 0;
+        const hipError_t e = chunk_geometry_k(p, &cus, &wgs);
+        if (e != hipSuccess) return (int)e;
+        out[2] = 1; out[3] = p.Lc; out[4] = p.NC; out[5] = p.RB; out[6] = cus; out[7] = wgs;
+    }
+    return 0;
+}
+
 extern "C" size_t ddsp_osc_scratch_bytes(int B, int T, int H)
 {
     if (B <= 0 || T <= 0 || H <= 0) return 0;

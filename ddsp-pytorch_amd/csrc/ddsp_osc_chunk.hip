@@ -12,10 +12,13 @@
 //     (clamped at both clip ends).  Crossing into the next segment costs one row of increments and amplitudes;
 //     the fp64 accumulators, the older row and everything else stay in registers.  Per-frame work of the frame
 //     kernels that is gone: the start-phase loads, the range check's three extra rows, the second segment load.
-//   * Per-sample work shared by a lane's harmonics is (almost) gone too: the weights are built by the scalar unit,
-//     the loudness factor is applied once per output sample in the flush, not once per lane.
+//   * Per-sample work shared by a lane's harmonics shrinks too: the loudness factor is applied once per output
+//     sample in the flush, not once per lane and sample.
 //
-// Launches: osc_chunk_totals_kernel (rows w / amp, chunk totals, per-piece "live slots" class and piece totals),
+//   * Silent harmonics (above Nyquist, :31-32) are skipped per chunk: pass 1 records, per (row, chunk), the highest
+//     harmonic slot that is audible anywhere in the chunk; a wavefront walks 1/4, 1/2 or all of the K slots.
+//
+// Launches: osc_chunk_totals_kernel (rows w / amp, chunk totals, highest audible slot per row and chunk),
 // osc_chunk_scan_kernel (exclusive scan of the chunk totals along the row, flag reset), osc_chunk_synth_kernel
 // (audio), osc_chunk_synth_kernel<EXACT> (a <= 256-workgroup grid that returns at once unless a wavefront of the
 // fast kernel declined its chunk: phases beyond the fast modulo's exact range, negative or NaN increments).
@@ -25,6 +28,7 @@
 #include <stdint.h>
 
 #include <mutex>
+#include <stdlib.h>
 
 #include "ddsp_hip.h"
 #include "ddsp_internal.h"
@@ -34,34 +38,57 @@ using namespace ddsp_osc;
 
 namespace {
 
+#ifndef DDSP_TURN_EVERY
+#define DDSP_TURN_EVERY 8    // synth walk: samples between two looks at the clock (divides 32)
+#endif
 constexpr int kRow = 256 + 4;          // staging row: one float per thread of the workgroup, padded
 constexpr float kReuseMaxInc = 4.8f;   // quotient reuse: r = P - q*2pi32 stays exact while |r| < 8, i.e. increments < 8 - pi
 
 #define DDSP_STAGE_END() __builtin_amdgcn_sched_barrier(0)
 #define DDSP_WAVE_ORDER() do { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 
-// bits of v / 2^lg for odd v, 1 <= v < 2^lg <= 2^14 -- exact; integer operations on wave-uniform values (scalar unit)
-__device__ __forceinline__ unsigned dyadic_bits(unsigned v, int lg)
+// F.interpolate weights inside a segment (App. A item 4 for a power-of-two hop): sample n has w1 = (2n+1)/(2 hop), exact, and
+// advances by exactly 1/hop per sample; segment 0 has its source index clamped to 0: w1 = 0 throughout.  (Built by the
+// scalar unit instead -- 25 dependent SALU instructions per sample -- the walk ran 13 % slower: gpurun_out r04a.)
+__device__ __forceinline__ void segment_lambda(const OscParams &p, int n, bool clamp0, float &lam, float &dlam)
 {
-    const int top = 31 - __builtin_clz(v);
-    return ((unsigned)(126 - lg + top) << 23) + (v << (23 - top));
+    lam = clamp0 ? 0.0f : (float)(2 * n + 1) * p.inv2R;
+    dlam = clamp0 ? 0.0f : 2.0f * p.inv2R;
 }
 
-// F.interpolate weights of sample n of a segment (App. A item 4 for a power-of-two hop): w1 = (2n+1)/(2 hop), w0 = 1 - w1
-// = (2(hop-1-n)+1)/(2 hop), both exact.  Segment 0 has its source index clamped to 0 (w1 = 0, w0 = 1): `keep` = 0 and
-// `one` = bits of 1.0f there, ~0 and 0 elsewhere -- integer selects, so that the weights never leave the scalar registers.
-struct SegW { unsigned keep, one; };
-__device__ __forceinline__ SegW seg_w(bool clamp0)
+// Fair sharing of a SIMD among its resident wavefronts.  The instruction arbiter serves the highest user priority first and
+// the OLDEST wavefront among equals: three equal, always-ready wavefronts on a SIMD then finish at 0.55 / 0.77 / 1.0 of the
+// run (measured: tools/microbench/osc_stamps.py), and the last one walks alone at half the SIMD's throughput.  With ONE round of
+// resident wavefronts nothing backfills, so the wavefronts take turns instead: priority level (slot + epoch) mod 3 with `slot`
+// the hardware wave slot on the SIMD (HW_ID[3:0]: 0, 1, 2 when three are resident) and `epoch` = the 100 MHz wall clock in
+// units of about a twelfth of the kernel's expected run time (host: turn_shift), which every wavefront of the SIMD reads alike -- the three levels are always all different, each wavefront
+// holds each of them a third of the time, and all of them reach the end together.  (Rotating with a wavefront's own progress
+// instead drifts into equal levels, where age decides again: slot 0 still finished 25 % early.)
+__device__ __forceinline__ int wave_slot()
 {
-    SegW g;
-    g.keep = clamp0 ? 0u : ~0u;
-    g.one = clamp0 ? 0x3f800000u : 0u;
-    return g;
+    return __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));   // HW_REG_HW_ID, bits 3:0 = wave slot on the SIMD
 }
-__device__ __forceinline__ void segment_weights(int n, int R, int lgR, SegW g, float &w0, float &w1)
+__device__ __forceinline__ void take_turn(int slot, int nres, int shift)
 {
-    w1 = __uint_as_float(dyadic_bits(2u * (unsigned)n + 1u, lgR + 1) & g.keep);
-    w0 = __uint_as_float((dyadic_bits(2u * (unsigned)(R - 1 - n) + 1u, lgR + 1) & g.keep) | g.one);
+    const unsigned epoch = (unsigned)(__builtin_amdgcn_s_memrealtime() >> shift);
+    const unsigned turn = epoch + (unsigned)slot;
+    switch (nres >= 3 ? turn % 3u : (nres == 2 ? (turn & 1u) : 0u)) {   // (constant moduli; s_setprio takes an immediate)
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(2); break;
+    }
+}
+
+// Element `idx` of a scratch array through a 32-bit byte offset (chunked_eligible keeps B*T*H below 2^29 elements): the
+// address is uniform base + per-lane 32-bit offset, which costs one register per access instead of a 64-bit pair -- with
+// 64-bit per-slot addresses the compiler spilled them and reloaded each one behind a full s_waitcnt at every segment.
+__device__ __forceinline__ float ldf(const float *base, unsigned idx)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (size_t)(idx * 4u));
+}
+__device__ __forceinline__ double ldd(const double *base, unsigned idx)
+{
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (size_t)(idx * 8u));
 }
 
 template <int K>
@@ -109,19 +136,31 @@ __device__ __forceinline__ void segment_rows(int s, int T, int &r0, int &r1)
 // computed on even samples and reused on the odd ones (increments < kReuseMaxInc, checked by the caller).
 // Every lane parks its partial sum in LDS; after each 32nd sample the G lanes of a row group each sum the partials of
 // 32/G samples, apply the loudness and store: one whole 128-byte line per row.
-template <int K, int KL, int NS, bool QKEEP>
+template <int K, int KL, int NS, int QMODE>
 __device__ __forceinline__ void walk_synth(const OscParams &p, ChunkState<K> &st, float *ystage, float *yrow, int j,
-                                           bool active, int i_abs, int n_beg, int n_end, bool clamp0, float L0, float L1)
+                                           bool active, int i_abs, int n_beg, int n_end, bool clamp0, float L0, float L1, int slot)
 {
     const int G = 1 << p.logG, per = 32 >> p.logG;
-    const SegW sw = seg_w(clamp0);
+    float lam, dlam;
+    segment_lambda(p, n_beg, clamp0, lam, dlam);
     float *ycol = ystage + threadIdx.x;
     const float *yblk = ystage + (threadIdx.x & ~(G - 1));
-    float qk[QKEEP ? KL : 1];
-    for (int n = n_beg; n < n_end; n += NS) {
+    static_assert(QMODE == 0 || (QMODE == 1 && NS == 1) || (QMODE == 2 && NS == 2), "quotient reuse: across iterations or inside a pair");
+    float qk[QMODE == 1 ? KL : 1];
+    // (pieces are multiples of 32 samples; the turn-taking and the flush sit BETWEEN runs of 8 samples so that the sample body
+    // stays one basic block -- with a branch inside it the compiler re-interleaved the stages: 4.15 instead of 3.8 cycles per
+    // VALU instruction)
+    constexpr int RUN = DDSP_TURN_EVERY < NS ? NS : DDSP_TURN_EVERY;
+    for (int nb = n_beg; nb < n_end; nb += RUN) {
+    take_turn(slot, p.nres, p.turn_shift);
+    for (int n = nb; n < nb + RUN; n += NS) {
         float w0[NS], w1[NS];
 #pragma unroll
-        for (int e = 0; e < NS; ++e) segment_weights(n + e, p.R, p.lgR, sw, w0[e], w1[e]);
+        for (int e = 0; e < NS; ++e) {
+            w1[e] = lam;
+            w0[e] = 1.0f - lam;
+            lam += dlam;
+        }
         float v[NS][KL];
         DDSP_STAGE_END();
 #pragma unroll
@@ -155,21 +194,26 @@ __device__ __forceinline__ void walk_synth(const OscParams &p, ChunkState<K> &st
         DDSP_STAGE_END();
         // P - q*2pi32 is exact in fp32 for q = rint(P/2pi32) < 2^21; nearest multiple instead of floor
         float q[NS][KL];
-        const bool fresh = !QKEEP || (n & 1) == 0;   // wave-uniform
+        const bool fresh = QMODE != 1 || (n & 1) == 0;   // wave-uniform
         if (fresh) {
+            constexpr int NQ = QMODE == 2 ? 1 : NS;
 #pragma unroll
-            for (int e = 0; e < NS; ++e)
+            for (int e = 0; e < NQ; ++e)
 #pragma unroll
                 for (int m = 0; m < KL; ++m) q[e][m] = __fmaf_rn(v[e][m], kInvTwoPi32, kRoundMagic);
             DDSP_STAGE_END();
 #pragma unroll
-            for (int e = 0; e < NS; ++e)
+            for (int e = 0; e < NQ; ++e)
 #pragma unroll
                 for (int m = 0; m < KL; ++m) q[e][m] = q[e][m] - kRoundMagic;
             DDSP_STAGE_END();
-            if (QKEEP) {
+            if (QMODE == 1) {
 #pragma unroll
                 for (int m = 0; m < KL; ++m) qk[m] = q[0][m];
+            }
+            if (QMODE == 2) {
+#pragma unroll
+                for (int m = 0; m < KL; ++m) q[NS - 1][m] = q[0][m];
             }
         } else {
 #pragma unroll
@@ -209,7 +253,9 @@ __device__ __forceinline__ void walk_synth(const OscParams &p, ChunkState<K> &st
         const int ia = i_abs + (n - n_beg);
 #pragma unroll
         for (int e = 0; e < NS; ++e) ycol[((ia + e) & 31) * kRow] = s0[e] + s1[e];
-        if (((ia + NS - 1) & 31) == 31) {
+    }
+        const int ia_end = i_abs + (nb + RUN - n_beg);   // absolute index one past the run
+        if ((ia_end & 31) == 0) {
             DDSP_WAVE_ORDER();
             // 32 samples x G partials per row group = 32 floats per lane whatever G is: float4 number f of lane j holds
             // lanes 4*(f mod G/4).. of sample j*per + f / (G/4)
@@ -220,7 +266,7 @@ __device__ __forceinline__ void walk_synth(const OscParams &p, ChunkState<K> &st
                 const float4 t4 = *reinterpret_cast<const float4 *>(yblk + (j * per + (f >> lgq)) * kRow + ((f & ((1 << lgq) - 1)) << 2));
                 t[f] = (t4.x + t4.y) + (t4.z + t4.w);
             }
-            const int nblk = n + NS - 32;        // segment offset of the block's first sample
+            const int nblk = nb + RUN - 32;      // segment offset of the block's first sample
             // loudness of a sample: fma(w0, L0, fl32(w1*L1)) like every other upsampled control (:46)
             auto loud = [&](int u) {
                 const int nl = nblk + j * per + u;
@@ -228,7 +274,7 @@ __device__ __forceinline__ void walk_synth(const OscParams &p, ChunkState<K> &st
                 if (clamp0) { lw1 = 0.0f; lw0 = 1.0f; }
                 return __fmaf_rn(lw0, L0, lw1 * L1);
             };
-            float *dst = yrow + (ia + NS - 32) + j * per;
+            float *dst = yrow + (ia_end - 32) + j * per;
             if (p.logG == 2) {
                 float o[8];
 #pragma unroll
@@ -258,10 +304,11 @@ template <int K>
 __device__ __forceinline__ void walk_synth_exact(const OscParams &p, ChunkState<K> &st, float *yrow, int j, bool active,
                                                  int i_abs, int n_beg, int n_end, bool clamp0, float L0, float L1)
 {
-    const SegW sw = seg_w(clamp0);
+    float lam, dlam;
+    segment_lambda(p, n_beg, clamp0, lam, dlam);
     for (int n = n_beg; n < n_end; ++n) {
-        float w0, w1;
-        segment_weights(n, p.R, p.lgR, sw, w0, w1);
+        const float w1 = lam, w0 = 1.0f - lam;
+        lam += dlam;
         float sum = 0.0f;
 #pragma unroll
         for (int m = 0; m < K; ++m) {
@@ -279,12 +326,15 @@ __device__ __forceinline__ void walk_synth_exact(const OscParams &p, ChunkState<
 // frame totals' chain only (increment, fp64 accumulate) over all K slots
 template <int K>
 __device__ __forceinline__ void walk_totals(const OscParams &p, double (&acc)[K], const float (&x0)[K], const float (&x1)[K],
-                                            int n_beg, int n_end, bool clamp0)
+                                            int n_beg, int n_end, bool clamp0, int slot)
 {
-    const SegW sw = seg_w(clamp0);
-    for (int n = n_beg; n < n_end; ++n) {
-        float w0, w1;
-        segment_weights(n, p.R, p.lgR, sw, w0, w1);
+    float lam, dlam;
+    segment_lambda(p, n_beg, clamp0, lam, dlam);
+    for (int nb = n_beg; nb < n_end; nb += 16) {
+    take_turn(slot, p.nres, p.turn_shift - 2);
+    for (int n = nb; n < nb + 16; ++n) {
+        const float w1 = lam, w0 = 1.0f - lam;
+        lam += dlam;
         float v[K];
         DDSP_STAGE_END();
 #pragma unroll
@@ -301,23 +351,17 @@ __device__ __forceinline__ void walk_totals(const OscParams &p, double (&acc)[K]
         for (int m = 0; m < K; ++m) acc[m] += d[m];
         DDSP_STAGE_END();
     }
+    }
 }
 
-// "live slots" class of a piece: 0 = the wavefront's audible harmonics sit in the first quarter of the slots, 1 = first
-// half, 2 = anywhere.  A slot is audible if any lane's amplitude at either bracketing row is not exactly zero (NaN counts);
-// nz0 / nz1: this lane's per-slot "amplitude != 0" bits of the two rows.
-template <int K>
-__device__ __forceinline__ int live_class(unsigned nz0, unsigned nz1)
+// OR over the G lanes of a row group
+__device__ __forceinline__ unsigned group_or(unsigned v, int logG)
 {
-    constexpr int KQ = (K + 3) / 4, KH = (K + 1) / 2;
-    unsigned any = nz0 | nz1;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) any |= (unsigned)__shfl_xor((int)any, o);
-    const int mlive = any ? 32 - __builtin_clz(any) : 0;
-    return mlive <= KQ ? 0 : (mlive <= KH ? 1 : 2);
+    for (int o = 1; o < (1 << logG); o <<= 1) v |= (unsigned)__shfl_xor((int)v, o);
+    return v;
 }
 
-// ---- pass 1: rows, chunk totals, piece classes / totals ---------------------------------------------------------
+// ---- pass 1: rows, chunk totals, highest audible slot ----------------------------------------------------------
 template <int K>
 __global__ void __launch_bounds__(256, K <= 13 ? 3 : 1) osc_chunk_totals_kernel(OscParams p)
 {
@@ -327,158 +371,240 @@ __global__ void __launch_bounds__(256, K <= 13 ? 3 : 1) osc_chunk_totals_kernel(
     const int G = 1 << p.logG;
     const long rowbase = (long)k.b * p.T;
     const int i_beg = k.i;
+    const int slot = wave_slot();
+    unsigned nz = 0u;   // this lane's slots with a non-zero amplitude (NaN counts) at any row the chunk interpolates from
 
     // row r of this lane's batch row: increments (:26-35) and masked, normalised amplitudes (:31-33); stored by the
     // chunk in which the row first becomes the NEWER row of a segment (every row exactly once)
-    auto make_row = [&](int r, float (&w)[K], unsigned &nz) {
+    auto make_row = [&](int r, float (&w)[K]) {
         const float fb = p.f0[rowbase + r];
-        const float *crow = p.c + (rowbase + r) * p.H;
+        const unsigned crow = ((unsigned)k.b * p.T + r) * p.H;
         float a0[K];
         float s = 0.0f;
+#pragma unroll
+        for (int m = 0; m < K; ++m) a0[m] = ldf(p.c, crow + min(k.j + m * G, p.H - 1));   // unconditional, inside the caller's tensor
 #pragma unroll
         for (int m = 0; m < K; ++m) {
             const int h = k.j + m * G;
             const bool ok = h < p.H;
             const float hz = (float)(h + 1) * fb;
-            a0[m] = (ok && !(hz > p.nyquist)) ? crow[h] : 0.0f;   // :31-32 strict >, integer Nyquist
+            a0[m] = (ok && !(hz > p.nyquist)) ? a0[m] : 0.0f;     // :31-32 strict >, integer Nyquist
             s += a0[m];
         }
         s = group_sum(s, p.logG);                                  // any summation order: App. A item 2
         const float rs = 1.0f / s;                                 // 0 * inf = NaN for an all-masked frame (:33)
         const int seg_start = max(r * p.R - (p.R >> 1), 0);
         const bool own = k.active && seg_start >= i_beg && seg_start < k.i_end;
-        nz = 0u;
 #pragma unroll
         for (int m = 0; m < K; ++m) {
             const int h = k.j + m * G;
             const bool ok = h < p.H;
             w[m] = ok ? frame_increment(h, fb, p.sr) : 0.0f;
             const float amp = ok ? a0[m] * rs : 0.0f;
-            if (amp != 0.0f) nz |= 1u << m;                        // NaN counts as audible
+            if (amp != 0.0f) nz |= 1u << m;
             if (ok && own) {
-                p.w[(rowbase + r) * p.H + h] = w[m];
-                p.amp[(rowbase + r) * p.H + h] = amp;
+                p.w[crow + h] = w[m];
+                p.amp[crow + h] = amp;
             }
         }
     };
 
     float x0[K], x1[K];
-    unsigned nz0, nz1;
     int r0, r1;
     segment_rows(k.s, p.T, r0, r1);
-    make_row(r0, x0, nz0);
-    make_row(r1, x1, nz1);
-    double ctot[K];
+    make_row(r0, x0);
+    make_row(r1, x1);
+    double acc[K];
 #pragma unroll
-    for (int m = 0; m < K; ++m) ctot[m] = 0.0;
-    int piece = 0;
+    for (int m = 0; m < K; ++m) acc[m] = 0.0;
     while (true) {
         const int n_end = min(p.R, k.n + (k.i_end - k.i));
-        const int cls = live_class<K>(nz0, nz1);
-        if ((threadIdx.x & 63) == 0) p.klive[(long)wt * p.P + piece] = cls;
-        double acc[K];
-#pragma unroll
-        for (int m = 0; m < K; ++m) acc[m] = 0.0;
-        walk_totals<K>(p, acc, x0, x1, k.n, n_end, k.s == 0);
-#pragma unroll
-        for (int m = 0; m < K; ++m) ctot[m] += acc[m];
-        if (cls < 2 && k.active) {
-            // the synth kernel skips this piece's silent slots and advances their accumulators by these totals
-            double *tp = p.tot + ((long)k.b * (p.T + 1 + p.NC) + (k.s + k.c)) * p.H;
-#pragma unroll
-            for (int m = 0; m < K; ++m) {
-                const int h = k.j + m * G;
-                if (h < p.H) tp[h] = acc[m];
-            }
-        }
+        walk_totals<K>(p, acc, x0, x1, k.n, n_end, k.s == 0, slot);
         k.i += n_end - k.n;
         if (k.i >= k.i_end) break;
-        ++k.s; ++piece; k.n = 0;
+        ++k.s; k.n = 0;
         if (k.s >= 2) {
 #pragma unroll
             for (int m = 0; m < K; ++m) x0[m] = x1[m];
-            nz0 = nz1;
-            if (k.s <= p.T - 1) make_row(k.s, x1, nz1);
+            if (k.s <= p.T - 1) make_row(k.s, x1);
         }
     }
+    nz = group_or(nz, p.logG);
     if (k.active) {
-        double *cp = p.ctot + ((long)k.b * p.NC + k.c) * p.H;
+        double *cp = p.ctot + (long)k.b * p.H * p.NC + (long)k.c * p.ct_sc;
 #pragma unroll
         for (int m = 0; m < K; ++m) {
             const int h = k.j + m * G;
-            if (h < p.H) cp[h] = ctot[m];
+            if (h < p.H) cp[(long)h * p.ct_sh] = acc[m];
         }
+        if (k.j == 0) p.rlive[(long)k.b * p.NC + k.c] = nz ? 32 - __builtin_clz(nz) : 0;
     }
 }
 
-// ---- pass 2: exclusive scan of the chunk totals along the row (B*H columns, NC steps; exact fp64 sums) ----------
-__global__ void __launch_bounds__(256) osc_chunk_scan_kernel(OscParams p)
+// ---- pass 2: exclusive scan of the chunk totals along the row; rows ordered by audible slots; flag reset --------------
+// The first nscan_waves wavefronts scan the columns (exact fp64 sums, so the order of the additions is free); the next NC
+// wavefronts take one chunk index each: perm[c][.] = the batch rows ordered by the class of their highest
+// audible slot in chunk c (all K slots first, then 3/4, 1/2, 1/4, 1/8), so that the rows a synth wavefront walks together
+// stop at the same slot; entries past B are -1.
+__global__ void __launch_bounds__(256) osc_chunk_scan_kernel(OscParams p, int nscan_waves)
 {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx == 0) *p.redo_flag = 0;
-    if (idx >= (long)p.B * p.H) return;
-    const int b = (int)(idx / p.H), h = (int)(idx - (long)b * p.H);
-    double *col = p.ctot + (long)b * p.NC * p.H + h;
-    double run = 0.0;
-    for (int s0 = 0; s0 < p.NC; s0 += 16) {   // sixteen independent loads per round trip; the additions keep their order
-        double v[16];
+    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wv == 0 && lane == 0) *p.redo_flag = 0;
+    const long ncol = (long)p.B * p.H;
+    if (wv < nscan_waves) {
+        if (p.ct_sc == 1) {
+            // many chunks, layout [B][H][NC]: one wavefront per (b,h) column, 64 chunks per step
+            double *col = p.ctot + wv * p.NC;
+            double carry = 0.0;
+            for (int c0 = 0; c0 < p.NC; c0 += 64) {
+                const int c = c0 + lane;
+                const double v = c < p.NC ? col[c] : 0.0;
+                double incl = v;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = (s0 + i < p.NC) ? col[(long)(s0 + i) * p.H] : 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (s0 + i < p.NC) {
-                col[(long)(s0 + i) * p.H] = run;
-                run += v[i];
+                for (int o = 1; o < 64; o <<= 1) {
+                    const double up = __shfl_up(incl, o);
+                    if (lane >= o) incl += up;
+                }
+                if (c < p.NC) col[c] = carry + (incl - v);
+                carry += __shfl(incl, 63);
             }
+        } else {
+            // few chunks, layout [B][NC][H]: one lane per column, sixteen independent loads per round trip
+            const long idx = wv * 64 + lane;
+            if (idx >= ncol) return;
+            const int b = (int)(idx / p.H), h = (int)(idx - (long)b * p.H);
+            double *col = p.ctot + (long)b * p.NC * p.H + h;
+            double run = 0.0;
+            for (int s0 = 0; s0 < p.NC; s0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = (s0 + i < p.NC) ? col[(long)(s0 + i) * p.H] : 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (s0 + i < p.NC) {
+                        col[(long)(s0 + i) * p.H] = run;
+                        run += v[i];
+                    }
+            }
+        }
+        return;
     }
+    const int c = (int)(wv - nscan_waves);
+    if (c >= p.NC) return;
+    const int Bpad = p.RB * (64 >> p.logG);
+    int *out = p.perm + (long)c * Bpad;
+    const int K = p.K;
+    const int lim[4] = {(3 * K + 3) / 4, (K + 1) / 2, (K + 3) / 4, (K + 7) / 8};   // osc_chunk_synth_kernel: KT, KH, KQ, KE
+    auto cls_of = [&](int ml) {   // 0 = walks every slot ... 4 = an eighth; -1 = no such row
+        if (ml < 0) return -1;
+        int q = 0;
+        while (q < 4 && ml <= lim[q]) ++q;
+        return q;
+    };
+    int base[5], cnt[5] = {0, 0, 0, 0, 0};
+    for (int b0 = 0; b0 < p.B; b0 += 64) {
+        const int b = b0 + lane;
+        const int cls = cls_of(b < p.B ? p.rlive[(long)b * p.NC + c] : -1);
+        for (int q = 0; q < 5; ++q) cnt[q] += __popcll(__ballot(cls == q));
+    }
+    base[0] = 0;
+    for (int q = 1; q < 5; ++q) base[q] = base[q - 1] + cnt[q - 1];
+    for (int b0 = 0; b0 < p.B; b0 += 64) {
+        const int b = b0 + lane;
+        const int cls = cls_of(b < p.B ? p.rlive[(long)b * p.NC + c] : -1);
+        for (int q = 0; q < 5; ++q) {
+            const unsigned long long mask = __ballot(cls == q);
+            if (cls == q) out[base[q] + __popcll(mask & ((1ull << lane) - 1ull))] = b;
+            base[q] += __popcll(mask);
+        }
+    }
+    for (int b = p.B + lane; b < Bpad; b += 64) out[b] = -1;
 }
+
+#ifdef DDSP_CHUNK_STAMPS
+// tuning builds only (tools/build_variant.sh ... -DDDSP_CHUNK_STAMPS): per wave task {start, end} of the synth walk on the
+// 100 MHz wall clock, HW_ID, XCC_ID -- read back with ddsp_osc_read_stamps
+__device__ long g_stamps[16384 * 4];
+extern "C" int ddsp_osc_read_stamps(long *host, int ntasks)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(long) * 4 * (size_t)(ntasks < 16384 ? ntasks : 16384));
+}
+#endif
 
 // ---- pass 3: synthesis --------------------------------------------------------------------------------------------
 template <int K, bool EXACT>
 __global__ void __launch_bounds__(256, (!EXACT && K <= 13) ? 3 : 1) osc_chunk_synth_kernel(OscParams p)
 {
     extern __shared__ float ystage[];   // [32][kRow] (fast kernel only)
-    constexpr int KQ = (K + 3) / 4, KH = (K + 1) / 2;
+    constexpr int KE = (K + 7) / 8, KQ = (K + 3) / 4, KH = (K + 1) / 2, KT = (3 * K + 3) / 4;   // walk lengths below K
     const int ntasks = p.RB * p.NC;
     int wt = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (EXACT && *p.redo_flag == 0) return;
     for (; wt < ntasks; wt += gridDim.x * 4) {
         if (EXACT && p.redo[wt] == 0) continue;
+#ifdef DDSP_CHUNK_STAMPS
+        const long stamp0 = wall_clock64();
+#endif
         Task k = decode_task(p, wt);
+        {   // the rows of this chunk index in the order of pass 2 (rows that stop at the same slot share a wavefront)
+            const int idx = k.rb * (64 >> p.logG) + ((threadIdx.x & 63) >> p.logG);
+            const int b = p.perm[(long)k.c * (p.RB * (64 >> p.logG)) + idx];
+            k.active = b >= 0;
+            k.b = k.active ? b : p.perm[(long)k.c * (p.RB * (64 >> p.logG))];
+        }
         const int G = 1 << p.logG;
         const long rowbase = (long)k.b * p.T;
         float *yrow = p.y + (long)k.b * p.T * p.R;
         ChunkState<K> st;
+        const int slot = EXACT ? 0 : wave_slot();
         bool bad = false;   // per lane: increments negative / NaN, phases beyond the fast modulo's range
+        // (padded slots, h >= H, read harmonic H-1 and are zeroed by a select: every load is unconditional, so the compiler
+        // issues them back to back instead of one exec-masked branch per element)
+        // (padded slots, h >= H, read whatever follows inside the scratch buffer and are zeroed by a select: every load is
+        // unconditional, so the compiler issues them back to back instead of one exec-masked branch per element)
+        const unsigned cbase = (unsigned)k.b * p.H * p.NC + (unsigned)k.j * p.ct_sh + (unsigned)k.c * p.ct_sc;
 #pragma unroll
         for (int m = 0; m < K; ++m) {
-            const int h = k.j + m * G;
-            st.acc[m] = (h < p.H) ? p.ctot[((long)k.b * p.NC + k.c) * p.H + h] : 0.0;
+            const double v = ldd(p.ctot, cbase + (unsigned)(m * G) * p.ct_sh);
+            st.acc[m] = (k.j + m * G < p.H) ? v : 0.0;
+            bad = bad || !(st.acc[m] >= 0.0);
+        }
+        // slots above the highest audible one of the wavefront's rows are silent for the whole chunk and their phase feeds
+        // nothing else (the next chunk starts from the scanned totals): walk 1/8, 1/4, 1/2, 3/4 or all of the K slots
+        int mlive = K;
+        if (!EXACT) {
+            mlive = p.rlive[(long)k.b * p.NC + k.c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mlive = max(mlive, __shfl_xor(mlive, o));
+            mlive = __builtin_amdgcn_readfirstlane(mlive);
         }
         int r0, r1;
         segment_rows(k.s, p.T, r0, r1);
         float L0, L1;
         auto load_rows = [&](int ra, int rb2, bool first) {
-            const float *w1row = p.w + (rowbase + rb2) * p.H;
-            const float *a0row = p.amp + (rowbase + ra) * p.H;
-            const float *a1row = p.amp + (rowbase + rb2) * p.H;
-            const float *w0row = p.w + (rowbase + ra) * p.H;
+            const unsigned o0 = ((unsigned)k.b * p.T + ra) * p.H + k.j, o1 = ((unsigned)k.b * p.T + rb2) * p.H + k.j;
+            float t0[K], t1[K], u0[K], u1[K];
 #pragma unroll
             for (int m = 0; m < K; ++m) {
-                const int h = k.j + m * G;
-                const bool ok = h < p.H;
-                if (first) st.x0[m] = ok ? w0row[h] : 0.0f;
-                st.x1[m] = ok ? w1row[h] : 0.0f;
-                const float u0 = ok ? a0row[h] : 0.0f;
-                const float u1 = ok ? a1row[h] : 0.0f;
-                st.a0[m] = u0;
-                st.da[m] = u1 - u0;
+                const unsigned g = (unsigned)(m * G);
+                t0[m] = first ? ldf(p.w, o0 + g) : 0.0f;
+                t1[m] = ldf(p.w, o1 + g);
+                u0[m] = ldf(p.amp, o0 + g);
+                u1[m] = ldf(p.amp, o1 + g);
+            }
+#pragma unroll
+            for (int m = 0; m < K; ++m) {
+                const bool ok = k.j + m * G < p.H;
+                if (first) st.x0[m] = ok ? t0[m] : 0.0f;
+                st.x1[m] = ok ? t1[m] : 0.0f;
+                st.a0[m] = ok ? u0[m] : 0.0f;
+                st.da[m] = ok ? u1[m] - u0[m] : 0.0f;
             }
             L0 = p.a[rowbase + ra];
             L1 = p.a[rowbase + rb2];
         };
         load_rows(r0, r1, true);
-        int piece = 0;
         while (true) {
             const int n_end = min(p.R, k.n + (k.i_end - k.i));
             const bool clamp0 = k.s == 0;
@@ -490,31 +616,22 @@ __global__ void __launch_bounds__(256, (!EXACT && K <= 13) ? 3 : 1) osc_chunk_sy
             }
             if (EXACT) {
                 walk_synth_exact<K>(p, st, yrow, k.j, k.active, k.i, k.n, n_end, clamp0, L0, L1);
+            } else if (mlive <= KE && KE < KQ) {
+                walk_synth<K, KE, 4, 0>(p, st, ystage, yrow, k.j, k.active, k.i, k.n, n_end, clamp0, L0, L1, slot);
+            } else if (mlive <= KQ && KQ < KH) {
+                walk_synth<K, KQ, 4, 0>(p, st, ystage, yrow, k.j, k.active, k.i, k.n, n_end, clamp0, L0, L1, slot);
+            } else if (mlive <= KH && KH < KT) {
+                walk_synth<K, KH, 2, 0>(p, st, ystage, yrow, k.j, k.active, k.i, k.n, n_end, clamp0, L0, L1, slot);
+            } else if (mlive <= KT && KT < K) {
+                walk_synth<K, KT, 1, 0>(p, st, ystage, yrow, k.j, k.active, k.i, k.n, n_end, clamp0, L0, L1, slot);
+            } else if (!__any(big)) {
+                walk_synth<K, K, 1, 1>(p, st, ystage, yrow, k.j, k.active, k.i, k.n, n_end, clamp0, L0, L1, slot);
             } else {
-                const int cls = __builtin_amdgcn_readfirstlane(p.klive[(long)wt * p.P + piece]);
-                if (cls == 0 && KQ < K) {
-                    walk_synth<K, KQ, 4, false>(p, st, ystage, yrow, k.j, k.active, k.i, k.n, n_end, clamp0, L0, L1);
-                } else if (cls <= 1 && KH < K) {
-                    walk_synth<K, KH, 2, false>(p, st, ystage, yrow, k.j, k.active, k.i, k.n, n_end, clamp0, L0, L1);
-                } else if (!__any(big)) {
-                    walk_synth<K, K, 1, true>(p, st, ystage, yrow, k.j, k.active, k.i, k.n, n_end, clamp0, L0, L1);
-                } else {
-                    walk_synth<K, K, 1, false>(p, st, ystage, yrow, k.j, k.active, k.i, k.n, n_end, clamp0, L0, L1);
-                }
-                if (cls < 2) {
-                    // silent slots were not walked: advance their accumulators by the piece totals of pass 1
-                    const int kl = (cls == 0 && KQ < K) ? KQ : ((KH < K) ? KH : K);
-                    const double *tp = p.tot + ((long)k.b * (p.T + 1 + p.NC) + (k.s + k.c)) * p.H;
-#pragma unroll
-                    for (int m = 0; m < K; ++m) {
-                        const int h = k.j + m * G;
-                        if (m >= kl && h < p.H) st.acc[m] += tp[h];
-                    }
-                }
+                walk_synth<K, K, 1, 0>(p, st, ystage, yrow, k.j, k.active, k.i, k.n, n_end, clamp0, L0, L1, slot);
             }
             k.i += n_end - k.n;
             if (k.i >= k.i_end) break;
-            ++k.s; ++piece; k.n = 0;
+            ++k.s; k.n = 0;
             if (k.s >= 2) {
 #pragma unroll
                 for (int m = 0; m < K; ++m) st.x0[m] = st.x1[m];
@@ -530,6 +647,14 @@ __global__ void __launch_bounds__(256, (!EXACT && K <= 13) ? 3 : 1) osc_chunk_sy
                 p.redo[wt] = redo ? 1 : 0;
                 if (redo) atomicOr(p.redo_flag, 1);
             }
+#ifdef DDSP_CHUNK_STAMPS
+            if ((threadIdx.x & 63) == 0 && wt < 16384) {
+                g_stamps[wt * 4 + 0] = stamp0;
+                g_stamps[wt * 4 + 1] = wall_clock64();
+                g_stamps[wt * 4 + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+                g_stamps[wt * 4 + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+            }
+#endif
         }
     }
 }
@@ -599,19 +724,20 @@ void pick_chunks(int T, int R, int RB, long slots, int *Lc_out, int *NC_out)
 
 bool chunked_eligible(const OscParams &p)
 {
-    return p.pow2 && p.R >= 64 && p.R <= 8192 && p.logG >= 2 && p.logG <= 4 && !p.live_in && !p.live_out && !p.dbg_phi;
+    return p.pow2 && p.R >= 64 && p.R <= 8192 && p.logG >= 2 && p.logG <= 4 && !p.live_in && !p.live_out && !p.dbg_phi &&
+           (long)p.B * p.T * p.H < (1L << 29);   // 32-bit byte offsets into the scratch arrays
 }
 
 size_t chunk_scratch_bytes(int B, int T, int H)
 {
     const size_t n = (size_t)B * T * H;
-    return 2 * align256(n * sizeof(float)) + align256(n * sizeof(double)) +
-           align256((size_t)B * (2 * (size_t)T + 1) * H * sizeof(double)) + align256((size_t)B * (4 * (size_t)T + 4) * sizeof(int)) +
-           align256((size_t)B * T * sizeof(int)) + 256;
+    // chunks are at least one hop long: NC <= T
+    return 2 * align256(n * sizeof(float)) + align256(n * sizeof(double)) + 2 * align256((size_t)B * T * sizeof(int)) +
+           align256((size_t)T * ((size_t)B + 16) * sizeof(int)) + 256;
 }
 
 template <int K>
-hipError_t launch_chunked(OscParams p, void *scratch, hipStream_t s)
+hipError_t chunk_geometry(OscParams &p, Residency *res_out)
 {
     Residency res;
     hipError_t e = synth_residency<K>(&res);
@@ -623,16 +749,41 @@ hipError_t launch_chunked(OscParams p, void *scratch, hipStream_t s)
     p.inv2R = 0.5f / (float)p.R;
     const long slots = (long)res.cus * res.wg_per_cu * 4;
     pick_chunks(p.T, p.R, p.RB, slots, &p.Lc, &p.NC);
-    p.P = p.Lc / p.R + 2;
-    // scratch: w | amp | ctot [B,NC,H] | tot [B,T+1+NC,H] | klive [RB*NC*P] | redo [RB*NC] | flag
+    if (ddsp_hooks_on()) {   // tuning experiments only (DDSP_TEST_HOOKS=1): force the chunk length
+        const char *e = getenv("DDSP_OSC_CHUNK_LEN");
+        const int v = e ? atoi(e) : 0;
+        if (v >= p.R && v % 32 == 0) {
+            p.Lc = v;
+            p.NC = (int)(((long)p.T * p.R + v - 1) / v);
+        }
+    }
+    if (p.NC > 96) { p.ct_sh = p.NC; p.ct_sc = 1; } else { p.ct_sh = 1; p.ct_sc = p.H; }   // [B][H][NC] or [B][NC][H]
+    p.nres = res.wg_per_cu < 3 ? (res.wg_per_cu < 1 ? 1 : res.wg_per_cu) : 3;
+    {   // turn-taking epoch = about 1/12 of the synth kernel's run: a chunk walk costs ~0.056 us per sample and harmonic slot
+        const double ticks = (double)p.Lc * (double)p.K * 5.6;   // 100 MHz ticks
+        int sh = 8;
+        while (sh < 16 && (double)(1 << (sh + 1)) <= ticks / 12.0) ++sh;
+        p.turn_shift = sh;
+    }
+    *res_out = res;
+    return hipSuccess;
+}
+
+template <int K>
+hipError_t launch_chunked(OscParams p, void *scratch, hipStream_t s)
+{
+    Residency res;
+    hipError_t e = chunk_geometry<K>(p, &res);
+    if (e != hipSuccess) return e;
+    // scratch: w | amp | ctot [B,H,NC] or [B,NC,H] | rlive [B,NC] | perm [NC, RB*64/G] | redo [RB*NC] | flag
     const size_t n = (size_t)p.B * p.T * p.H;
     char *base = (char *)scratch;
     p.w = (float *)base;
     p.amp = (float *)(base + align256(n * sizeof(float)));
     p.ctot = (double *)(base + 2 * align256(n * sizeof(float)));
-    p.tot = (double *)((char *)p.ctot + align256((size_t)p.B * p.NC * p.H * sizeof(double)));
-    p.klive = (int *)((char *)p.tot + align256((size_t)p.B * (p.T + 1 + p.NC) * p.H * sizeof(double)));
-    p.redo = (int *)((char *)p.klive + align256((size_t)p.RB * p.NC * p.P * sizeof(int)));
+    p.rlive = (int *)((char *)p.ctot + align256((size_t)p.B * p.NC * p.H * sizeof(double)));
+    p.perm = (int *)((char *)p.rlive + align256((size_t)p.B * p.NC * sizeof(int)));
+    p.redo = (int *)((char *)p.perm + align256((size_t)p.NC * p.RB * (64 >> p.logG) * sizeof(int)));
     p.redo_flag = (int *)((char *)p.redo + align256((size_t)p.RB * p.NC * sizeof(int)));
 
     const long tasks = (long)p.RB * p.NC;
@@ -641,7 +792,8 @@ hipError_t launch_chunked(OscParams p, void *scratch, hipStream_t s)
     hipLaunchKernelGGL((osc_chunk_totals_kernel<K>), dim3(grid), dim3(256), 0, s, p);
     ddsp_prof::end(slot, s);
     slot = ddsp_prof::begin(ddsp_prof::SCAN, s);
-    hipLaunchKernelGGL(osc_chunk_scan_kernel, dim3((unsigned)(((long)p.B * p.H + 255) / 256)), dim3(256), 0, s, p);
+    const long nscan_waves = p.ct_sc == 1 ? (long)p.B * p.H : ((long)p.B * p.H + 63) / 64;
+    hipLaunchKernelGGL(osc_chunk_scan_kernel, dim3((unsigned)((nscan_waves + p.NC + 3) / 4)), dim3(256), 0, s, p, (int)nscan_waves);
     ddsp_prof::end(slot, s);
     slot = ddsp_prof::begin(ddsp_prof::SYNTH, s);
     hipLaunchKernelGGL((osc_chunk_synth_kernel<K, false>), dim3(grid), dim3(256), sizeof(float) * 32 * kRow, s, p);
@@ -649,6 +801,21 @@ hipError_t launch_chunked(OscParams p, void *scratch, hipStream_t s)
     const unsigned rgrid = grid < 256u ? grid : 256u;
     hipLaunchKernelGGL((osc_chunk_synth_kernel<K, true>), dim3(rgrid), dim3(256), 0, s, p);
     return hipGetLastError();
+}
+
+hipError_t chunk_geometry_k(OscParams &p, int *cus, int *wg_per_cu)
+{
+    Residency res = {};
+    hipError_t e = hipErrorInvalidValue;
+    switch (p.K) {
+#define DDSP_CASE(KK) case KK: e = chunk_geometry<KK>(p, &res); break;
+        DDSP_CASE(4) DDSP_CASE(8) DDSP_CASE(12) DDSP_CASE(13) DDSP_CASE(15) DDSP_CASE(16) DDSP_CASE(20) DDSP_CASE(23) DDSP_CASE(25)
+#undef DDSP_CASE
+        default: break;
+    }
+    *cus = res.cus;
+    *wg_per_cu = res.wg_per_cu;
+    return e;
 }
 
 hipError_t launch_chunked_k(const OscParams &p, void *scratch, hipStream_t s)

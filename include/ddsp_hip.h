@@ -125,6 +125,10 @@ int ddsp_osc_set_tiling(int harmonics_per_lane);
 /* Test / tuning hook: 1 = frame kernels for every shape (the round 1-3 decomposition, one lane group per frame), 0 = automatic
  * (chunked form where it applies).  Same results within rounding. */
 int ddsp_osc_set_path(int path);
+/* What ddsp_osc_forward would launch for this shape on the current device (HOST array of >= 8 ints): out[0] harmonics per
+ * lane, [1] lanes per row group, [2] 1 = chunked form, then its [3] chunk length in samples, [4] chunks per row,
+ * [5] row blocks, [6] compute units and [7] resident workgroups per unit the chunk length was sized for. */
+int ddsp_osc_plan(int B, int T, int H, int hop, int sample_rate, int *out, int cap);
 
 /* Test / tuning hook (process-global, read once per launch): bit 0 forces the generic one-frame-per-workgroup noise kernels
  * (any hop) instead of the batched ones (hop % 8 == 0, tile fits LDS); bit 1 keeps the direct (time-domain) forms where the

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Only the oscillator at a BASELINE shape, N times (for rocprofv3 passes): osc_only.py <frame|chunk> [steps] [cfg4|cfg2|cfg3] [all_live|musical]"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+os.environ.setdefault("DDSP_TEST_HOOKS", "1")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import ddsp_pytorch_amd as ddsp  # noqa: E402
+from ddsp_pytorch_amd import synthetic as syn  # noqa: E402
+
+path = sys.argv[1] if len(sys.argv) > 1 else "chunk"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+shape = {"cfg4": syn.CFG4_PER_GPU, "cfg2": syn.CFG2, "cfg3": syn.CFG3}[sys.argv[3] if len(sys.argv) > 3 else "cfg4"]
+kind = sys.argv[4] if len(sys.argv) > 4 else "all_live"
+assert ddsp._lib.lib().ddsp_osc_set_path(1 if path == "frame" else 0) == 0
+ctl = syn.make_controls(shape, 1004, kind)
+x = {k: torch.from_numpy(v).cuda() for k, v in ctl.items() if k != "H"}
+plan = ddsp._lib.osc_plan(shape.batch, shape.frames, shape.n_harmonics, shape.hop, shape.sample_rate)
+
+
+def run():
+    return ddsp.osc_forward(x["f0"], x["c"], x["a"], shape.hop, shape.sample_rate)[0]
+
+
+for _ in range(2):
+    run()
+ddsp._lib.profile_enable(8 * steps + 8)
+torch.cuda.synchronize()
+for _ in range(steps):
+    y = run()
+torch.cuda.synchronize()
+rec = {}
+for name, ms in ddsp._lib.profile_read():
+    rec.setdefault(name, []).append(ms)
+print(json.dumps({"path": path, "config": shape.name, "f0": kind, "plan": plan, "env_chunk": os.environ.get("DDSP_OSC_CHUNK_LEN"),
+                  "kernel_ms": {k: round(float(np.mean(v)), 4) for k, v in rec.items()}}), flush=True)

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Per-wavefront start / end of the chunked synth kernel (library built with -DDDSP_CHUNK_STAMPS; DDSP_HIP_LIB points at it)."""
+import collections
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+os.environ.setdefault("DDSP_TEST_HOOKS", "1")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import ddsp_pytorch_amd as ddsp  # noqa: E402
+from ddsp_pytorch_amd import synthetic as syn  # noqa: E402
+
+shape = syn.CFG4_PER_GPU
+ctl = syn.make_controls(shape, 1004, "all_live")
+x = {k: torch.from_numpy(v).cuda() for k, v in ctl.items() if k != "H"}
+plan = ddsp._lib.osc_plan(shape.batch, shape.frames, shape.n_harmonics, shape.hop, shape.sample_rate)
+for _ in range(3):
+    ddsp.osc_forward(x["f0"], x["c"], x["a"], shape.hop, shape.sample_rate)
+torch.cuda.synchronize()
+n = plan["chunks_per_row"] * plan["row_blocks"]
+L = ddsp._lib.lib()
+buf = (ctypes.c_long * (4 * n))()
+L.ddsp_osc_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert L.ddsp_osc_read_stamps(buf, n) == 0
+a = np.frombuffer(buf, dtype=np.int64).reshape(n, 4)
+t0 = a[:, 0].min()
+start = (a[:, 0] - t0) / 100.0   # microseconds (100 MHz)
+end = (a[:, 1] - t0) / 100.0
+dur = end - start
+hw = a[:, 2]
+xcc = a[:, 3] & 0xf
+cu = (hw >> 8) & 0xf
+sh = (hw >> 12) & 1
+se = (hw >> 13) & 7
+simd = (hw >> 4) & 3
+wslot = hw & 0xf
+print("wave slots used:", collections.Counter(int(v) for v in wslot))
+print(json.dumps({"plan": plan, "tasks": int(n), "start_us": [float(start.min()), float(np.median(start)), float(start.max())],
+                  "end_us": [float(end.min()), float(np.median(end)), float(end.max())],
+                  "dur_us": [float(dur.min()), float(np.median(dur)), float(dur.max())]}))
+print("duration histogram (us):", np.histogram(dur, bins=12))
+print("start histogram (us):", np.histogram(start, bins=12))
+per = collections.defaultdict(list)
+for i in range(n):
+    per[int(xcc[i])].append(end[i])
+print("per XCC: n, median end, max end:", {k: (len(v), round(float(np.median(v)), 1), round(float(max(v)), 1)) for k, v in sorted(per.items())})
+slot = collections.Counter((int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i]), int(simd[i])) for i in range(n))
+print("waves per (xcc,se,sh,cu,simd): histogram of counts:", collections.Counter(slot.values()), "distinct SIMDs:", len(slot))
+cus = collections.Counter((int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i])) for i in range(n))
+print("waves per CU: histogram:", collections.Counter(cus.values()), "distinct CUs:", len(cus))
+for w in sorted(set(int(v) for v in wslot)):
+    print("wave slot", w, "n", int((wslot == w).sum()), "median end", round(float(np.median(end[wslot == w])), 1))
+# duration against co-residency
+cnt = np.array([slot[(int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i]), int(simd[i]))] for i in range(n)])
+for c in sorted(set(cnt)):
+    print("waves on a SIMD with", c, "tasks: n", int((cnt == c).sum()), "median dur", round(float(np.median(dur[cnt == c])), 1),
+          "median start", round(float(np.median(start[cnt == c])), 1))
