@@ -16,7 +16,8 @@
 //     sample in the flush, not once per lane and sample.
 //
 //   * Silent harmonics (above Nyquist, :31-32) are skipped per chunk: pass 1 records, per (row, chunk), the highest
-//     harmonic slot that is audible anywhere in the chunk; a wavefront walks 1/4, 1/2 or all of the K slots.
+//     harmonic slot that is audible anywhere in the chunk; a wavefront walks 1/8, 1/4, 1/2, 3/4 or all of the K slots, and pass 2 orders the rows
+//     of every chunk index so that rows which stop at the same slot share a wavefront.
 //
 // Launches: osc_chunk_totals_kernel (rows w / amp, chunk totals, highest audible slot per row and chunk),
 // osc_chunk_scan_kernel (exclusive scan of the chunk totals along the row, flag reset), osc_chunk_synth_kernel
@@ -431,58 +432,78 @@ __global__ void __launch_bounds__(256, K <= 13 ? 3 : 1) osc_chunk_totals_kernel(
     }
     nz = group_or(nz, p.logG);
     if (k.active) {
-        double *cp = p.ctot + (long)k.b * p.H * p.NC + (long)k.c * p.ct_sc;
+        double *cp = p.ctot + ((long)k.b * p.NC + k.c) * p.H;
 #pragma unroll
         for (int m = 0; m < K; ++m) {
             const int h = k.j + m * G;
-            if (h < p.H) cp[(long)h * p.ct_sh] = acc[m];
+            if (h < p.H) cp[h] = acc[m];
         }
         if (k.j == 0) p.rlive[(long)k.b * p.NC + k.c] = nz ? 32 - __builtin_clz(nz) : 0;
     }
 }
 
 // ---- pass 2: exclusive scan of the chunk totals along the row; rows ordered by audible slots; flag reset --------------
-// The first nscan_waves wavefronts scan the columns (exact fp64 sums, so the order of the additions is free); the next NC
-// wavefronts take one chunk index each: perm[c][.] = the batch rows ordered by the class of their highest
+// The first nscan_blocks workgroups scan the columns (exact fp64 sums, so the order of the additions is free); the wavefronts
+// of the others take one chunk index each: perm[c][.] = the batch rows ordered by the class of their highest
 // audible slot in chunk c (all K slots first, then 3/4, 1/2, 1/4, 1/8), so that the rows a synth wavefront walks together
 // stop at the same slot; entries past B are -1.
-__global__ void __launch_bounds__(256) osc_chunk_scan_kernel(OscParams p, int nscan_waves)
+__global__ void __launch_bounds__(256) osc_chunk_scan_kernel(OscParams p, int nscan_blocks, int Q)
 {
-    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (wv == 0 && lane == 0) *p.redo_flag = 0;
-    const long ncol = (long)p.B * p.H;
-    if (wv < nscan_waves) {
-        if (p.ct_sc == 1) {
-            // many chunks, layout [B][H][NC]: one wavefront per (b,h) column, 64 chunks per step
-            double *col = p.ctot + wv * p.NC;
-            double carry = 0.0;
-            for (int c0 = 0; c0 < p.NC; c0 += 64) {
-                const int c = c0 + lane;
-                const double v = c < p.NC ? col[c] : 0.0;
-                double incl = v;
+    __shared__ double seg_tot[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *p.redo_flag = 0;
+    if ((int)blockIdx.x < nscan_blocks) {
+        // 64 columns per workgroup, coalesced along h; the chunk range is cut into Q <= 4 segments, one per wavefront: first the
+        // segment totals (independent loads), then each segment's exclusive scan starting from the totals before it
+        const long ncol = (long)p.B * p.H;
+        const long idx = (long)blockIdx.x * 64 + lane;
+        const bool live = idx < ncol && q < Q;
+        const int b = live ? (int)(idx / p.H) : 0, h = live ? (int)(idx - (long)b * p.H) : 0;
+        double *col = p.ctot + (long)b * p.NC * p.H + h;
+        const int per = (p.NC + Q - 1) / Q, c_beg = q * per, c_end = min(c_beg + per, p.NC);
+        if (per <= 32) {
+            // the whole segment stays in registers between the two steps: one read, one write
+            double v[32];
+            double tot = 0.0;
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const double up = __shfl_up(incl, o);
-                    if (lane >= o) incl += up;
-                }
-                if (c < p.NC) col[c] = carry + (incl - v);
-                carry += __shfl(incl, 63);
+            for (int i = 0; i < 32; ++i) {
+                v[i] = (live && c_beg + i < c_end) ? col[(long)(c_beg + i) * p.H] : 0.0;
+                tot += v[i];
             }
-        } else {
-            // few chunks, layout [B][NC][H]: one lane per column, sixteen independent loads per round trip
-            const long idx = wv * 64 + lane;
-            if (idx >= ncol) return;
-            const int b = (int)(idx / p.H), h = (int)(idx - (long)b * p.H);
-            double *col = p.ctot + (long)b * p.NC * p.H + h;
+            seg_tot[q][lane] = tot;
+            __syncthreads();
             double run = 0.0;
-            for (int s0 = 0; s0 < p.NC; s0 += 16) {
+            for (int qq = 0; qq < q; ++qq) run += seg_tot[qq][lane];
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if (live && c_beg + i < c_end) {
+                    col[(long)(c_beg + i) * p.H] = run;
+                    run += v[i];
+                }
+            return;
+        }
+        double tot = 0.0;
+        if (live) {
+            for (int s0 = c_beg; s0 < c_end; s0 += 16) {
                 double v[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = (s0 + i < p.NC) ? col[(long)(s0 + i) * p.H] : 0.0;
+                for (int i = 0; i < 16; ++i) v[i] = (s0 + i < c_end) ? col[(long)(s0 + i) * p.H] : 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tot += v[i];
+            }
+        }
+        seg_tot[q][lane] = tot;
+        __syncthreads();
+        if (live) {
+            double run = 0.0;
+            for (int qq = 0; qq < q; ++qq) run += seg_tot[qq][lane];
+            for (int s0 = c_beg; s0 < c_end; s0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = (s0 + i < c_end) ? col[(long)(s0 + i) * p.H] : 0.0;
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    if (s0 + i < p.NC) {
+                    if (s0 + i < c_end) {
                         col[(long)(s0 + i) * p.H] = run;
                         run += v[i];
                     }
@@ -490,7 +511,8 @@ __global__ void __launch_bounds__(256) osc_chunk_scan_kernel(OscParams p, int ns
         }
         return;
     }
-    const int c = (int)(wv - nscan_waves);
+    const long wv = (long)(blockIdx.x - nscan_blocks) * 4 + q;
+    const int c = (int)wv;
     if (c >= p.NC) return;
     const int Bpad = p.RB * (64 >> p.logG);
     int *out = p.perm + (long)c * Bpad;
@@ -559,14 +581,13 @@ __global__ void __launch_bounds__(256, (!EXACT && K <= 13) ? 3 : 1) osc_chunk_sy
         ChunkState<K> st;
         const int slot = EXACT ? 0 : wave_slot();
         bool bad = false;   // per lane: increments negative / NaN, phases beyond the fast modulo's range
-        // (padded slots, h >= H, read harmonic H-1 and are zeroed by a select: every load is unconditional, so the compiler
         // issues them back to back instead of one exec-masked branch per element)
         // (padded slots, h >= H, read whatever follows inside the scratch buffer and are zeroed by a select: every load is
         // unconditional, so the compiler issues them back to back instead of one exec-masked branch per element)
-        const unsigned cbase = (unsigned)k.b * p.H * p.NC + (unsigned)k.j * p.ct_sh + (unsigned)k.c * p.ct_sc;
+        const unsigned cbase = ((unsigned)k.b * p.NC + k.c) * p.H + k.j;
 #pragma unroll
         for (int m = 0; m < K; ++m) {
-            const double v = ldd(p.ctot, cbase + (unsigned)(m * G) * p.ct_sh);
+            const double v = ldd(p.ctot, cbase + (unsigned)(m * G));
             st.acc[m] = (k.j + m * G < p.H) ? v : 0.0;
             bad = bad || !(st.acc[m] >= 0.0);
         }
@@ -690,27 +711,28 @@ hipError_t synth_residency(Residency *out)
 
 namespace ddsp_osc {
 
-// Chunk length for `slots` resident wavefronts: every (row block, chunk) task resident at once when the problem allows it
-// (one round: the run time is one chunk's walk), otherwise the number of chunks per row that wastes least in the last round.
-// c0 = fixed cost of a chunk in samples' worth of walking (prologue loads, first rows).
-void pick_chunks(int T, int R, int RB, long slots, int *Lc_out, int *NC_out)
+// Chunk length.  A compute unit takes whole workgroups (4 wavefronts, one per SIMD), at most `wg_per_cu` at a time, and a
+// SIMD's throughput is about the same with 2 or 3 resident wavefronts (half of it with 1): the run time is the number of
+// workgroups the fullest unit gets times one chunk's walk.  Preferred: every (row block, chunk) task resident at once and the
+// same number of workgroups on every unit; c0 = fixed cost of a chunk in samples' worth of walking (prologue loads, first rows).
+void pick_chunks(int T, int R, int RB, int cus, int wg_per_cu, int *Lc_out, int *NC_out)
 {
     const long N = (long)T * R;
-    const double c0 = 24.0;
+    const double c0 = 40.0;
     double best = 1e300;
     int bestLc = (int)N, bestNC = 1;
-    const int ncmax = T;   // chunks are at least one hop long
     int lastLc = -1;
-    for (int nc = 1; nc <= ncmax; ++nc) {
+    for (int nc = 1; nc <= T; ++nc) {   // chunks are at least one hop long
         long Lc = (N + nc - 1) / nc;
         Lc = (Lc + 31) & ~31L;
         if (Lc < R) Lc = R;
         if (Lc == lastLc) continue;
         lastLc = (int)Lc;
         const long NC = (N + Lc - 1) / Lc;
-        const long tasks = NC * RB;
-        const long rounds = (tasks + slots - 1) / slots;
-        const double cost = (double)rounds * ((double)Lc + c0);
+        const long wgs = (NC * RB + 3) / 4;
+        const long per_cu = (wgs + cus - 1) / cus;
+        const double alone = per_cu == 1 ? 1.9 : (per_cu == 2 ? 1.03 : 1.0);   // a lone wavefront gets half of the SIMD
+        const double cost = (double)per_cu * alone * ((double)Lc + c0);
         if (cost < best) {
             best = cost;
             bestLc = (int)Lc;
@@ -718,6 +740,7 @@ void pick_chunks(int T, int R, int RB, long slots, int *Lc_out, int *NC_out)
         }
         if (Lc == R) break;
     }
+    (void)wg_per_cu;
     *Lc_out = bestLc;
     *NC_out = bestNC;
 }
@@ -747,8 +770,7 @@ hipError_t chunk_geometry(OscParams &p, Residency *res_out)
     p.lgR = 0;
     while ((1 << p.lgR) < p.R) ++p.lgR;
     p.inv2R = 0.5f / (float)p.R;
-    const long slots = (long)res.cus * res.wg_per_cu * 4;
-    pick_chunks(p.T, p.R, p.RB, slots, &p.Lc, &p.NC);
+    pick_chunks(p.T, p.R, p.RB, res.cus, res.wg_per_cu, &p.Lc, &p.NC);
     if (ddsp_hooks_on()) {   // tuning experiments only (DDSP_TEST_HOOKS=1): force the chunk length
         const char *e = getenv("DDSP_OSC_CHUNK_LEN");
         const int v = e ? atoi(e) : 0;
@@ -757,7 +779,6 @@ hipError_t chunk_geometry(OscParams &p, Residency *res_out)
             p.NC = (int)(((long)p.T * p.R + v - 1) / v);
         }
     }
-    if (p.NC > 96) { p.ct_sh = p.NC; p.ct_sc = 1; } else { p.ct_sh = 1; p.ct_sc = p.H; }   // [B][H][NC] or [B][NC][H]
     p.nres = res.wg_per_cu < 3 ? (res.wg_per_cu < 1 ? 1 : res.wg_per_cu) : 3;
     {   // turn-taking epoch = about 1/12 of the synth kernel's run: a chunk walk costs ~0.056 us per sample and harmonic slot
         const double ticks = (double)p.Lc * (double)p.K * 5.6;   // 100 MHz ticks
@@ -775,7 +796,7 @@ hipError_t launch_chunked(OscParams p, void *scratch, hipStream_t s)
     Residency res;
     hipError_t e = chunk_geometry<K>(p, &res);
     if (e != hipSuccess) return e;
-    // scratch: w | amp | ctot [B,H,NC] or [B,NC,H] | rlive [B,NC] | perm [NC, RB*64/G] | redo [RB*NC] | flag
+    // scratch: w | amp | ctot [B,NC,H] | rlive [B,NC] | perm [NC, RB*64/G] | redo [RB*NC] | flag
     const size_t n = (size_t)p.B * p.T * p.H;
     char *base = (char *)scratch;
     p.w = (float *)base;
@@ -792,8 +813,9 @@ hipError_t launch_chunked(OscParams p, void *scratch, hipStream_t s)
     hipLaunchKernelGGL((osc_chunk_totals_kernel<K>), dim3(grid), dim3(256), 0, s, p);
     ddsp_prof::end(slot, s);
     slot = ddsp_prof::begin(ddsp_prof::SCAN, s);
-    const long nscan_waves = p.ct_sc == 1 ? (long)p.B * p.H : ((long)p.B * p.H + 63) / 64;
-    hipLaunchKernelGGL(osc_chunk_scan_kernel, dim3((unsigned)((nscan_waves + p.NC + 3) / 4)), dim3(256), 0, s, p, (int)nscan_waves);
+    const long nscan_blocks = ((long)p.B * p.H + 63) / 64;
+    const int Q = p.NC > 64 ? 4 : (p.NC > 32 ? 2 : 1);   // <= 32 chunks per wavefront up to 128 chunks: the register form
+    hipLaunchKernelGGL(osc_chunk_scan_kernel, dim3((unsigned)(nscan_blocks + (p.NC + 3) / 4)), dim3(256), 0, s, p, (int)nscan_blocks, Q);
     ddsp_prof::end(slot, s);
     slot = ddsp_prof::begin(ddsp_prof::SYNTH, s);
     hipLaunchKernelGGL((osc_chunk_synth_kernel<K, false>), dim3(grid), dim3(256), sizeof(float) * 32 * kRow, s, p);

@@ -36,7 +36,7 @@ struct OscParams {
     int stage_out;    // synth: stage 32 output samples per frame in LDS, store whole 128-byte lines (pow2 hop >= 64, G in 4..16)
     int pow2;         // hop is a power of two and the clip has <= 2^23 samples: incremental weights, uniform loops
     // chunked form (ddsp_osc_chunk.hip): power-of-two hop >= 64, 4..16 lanes per row group
-    double *ctot;     // scratch [B,NC,H] or [B,H,NC] (ct_sh, ct_sc): chunk totals, then (in place) their exclusive scan along the row
+    double *ctot;     // scratch [B,NC,H]: chunk totals, then (in place) their exclusive scan along the row
     int *rlive;       // scratch [B,NC]: 1 + highest harmonic slot with a non-zero amplitude anywhere in the row's chunk
     int *perm;        // scratch [NC, RB*64/G]: per chunk index, the batch rows grouped by how many slots they walk (-1 = none)
     int *redo;        // scratch [RB*NC]: wave tasks the fast synth kernel declined
@@ -44,7 +44,6 @@ struct OscParams {
     int lgR;          // log2(R)
     int nres;         // wavefronts per SIMD the chunks were sized for (turn-taking modulus, <= 3)
     int turn_shift;   // log2 of the turn-taking epoch in 100 MHz ticks
-    int ct_sh, ct_sc; // strides of ctot along h and along c (layout [B][NC][H] for few chunks, [B][H][NC] for many)
     float inv2R;      // 1/(2R)
     float scale;      // fl32(1/R): F.interpolate's source-index scale
     float nyquist;    // float(sample_rate // 2)
@@ -176,7 +175,7 @@ bool setup_params(OscParams &p, void *scratch, int B, int T, int H, int hop, int
 // chunked form (ddsp_osc_chunk.hip)
 bool chunked_eligible(const OscParams &p);
 size_t chunk_scratch_bytes(int B, int T, int H);
-void pick_chunks(int T, int R, int RB, long slots, int *Lc_out, int *NC_out);
+void pick_chunks(int T, int R, int RB, int cus, int wg_per_cu, int *Lc_out, int *NC_out);
 hipError_t launch_chunked_k(const OscParams &p, void *scratch, hipStream_t s);
 hipError_t chunk_geometry_k(OscParams &p, int *cus, int *wg_per_cu);
 

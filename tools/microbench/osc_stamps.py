@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 import ddsp_pytorch_amd as ddsp  # noqa: E402
 from ddsp_pytorch_amd import synthetic as syn  # noqa: E402
 
-shape = syn.CFG4_PER_GPU
+shape = {"cfg4": syn.CFG4_PER_GPU, "cfg2": syn.CFG2, "cfg3": syn.CFG3}[sys.argv[1] if len(sys.argv) > 1 else "cfg4"]
 ctl = syn.make_controls(shape, 1004, "all_live")
 x = {k: torch.from_numpy(v).cuda() for k, v in ctl.items() if k != "H"}
 plan = ddsp._lib.osc_plan(shape.batch, shape.frames, shape.n_harmonics, shape.hop, shape.sample_rate)
