@@ -591,6 +591,12 @@ bool pick_tiling(int H, long frames, Tiling *out)
     return found;
 }
 
+size_t frame_scratch_bytes(int B, int T, int H)
+{
+    const size_t n = (size_t)B * T * H;
+    return 2 * align256(n * sizeof(float)) + align256(n * sizeof(double)) + align256(sup_elems(B, T, H) * sizeof(double)) + 256;
+}
+
 bool setup_params(OscParams &p, void *scratch, int B, int T, int H, int hop, int sample_rate)
 {
     Tiling tl;
@@ -657,10 +663,7 @@ extern "C" int ddsp_osc_plan(int B, int T, int H, int hop, int sample_rate, int 
 extern "C" size_t ddsp_osc_scratch_bytes(int B, int T, int H)
 {
     if (B <= 0 || T <= 0 || H <= 0) return 0;
-    const size_t n = (size_t)B * T * H;
-    const size_t frame = 2 * align256(n * sizeof(float)) + align256(n * sizeof(double)) + align256(sup_elems(B, T, H) * sizeof(double)) + 256;
-    const size_t chunk = chunk_scratch_bytes(B, T, H);
-    return frame > chunk ? frame : chunk;
+    return chunk_scratch_bytes(B, T, H);   // = the frame layout + the chunked form's small arrays behind it
 }
 
 extern "C" int ddsp_osc_forward(const float *f0, const float *c, const float *a, float *y, void *scratch,

@@ -451,7 +451,10 @@ __global__ void __launch_bounds__(256) osc_chunk_scan_kernel(OscParams p, int ns
 {
     __shared__ double seg_tot[4][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *p.redo_flag = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *p.redo_flag = 0;
+        p.frame_flag[2] = 0;   // not a frame-form scratch (ddsp_osc_backward checks kFrameScratchTag here)
+    }
     if ((int)blockIdx.x < nscan_blocks) {
         // 64 columns per workgroup, coalesced along h; the chunk range is cut into Q <= 4 segments, one per wavefront: first the
         // segment totals (independent loads), then each segment's exclusive scan starting from the totals before it
@@ -751,11 +754,12 @@ bool chunked_eligible(const OscParams &p)
            (long)p.B * p.T * p.H < (1L << 29);   // 32-bit byte offsets into the scratch arrays
 }
 
+// The chunked layout keeps the frame layout's first parts (w | amp | fp64 region: ctot [B,NC,H] fits where loc [B,T,H] sits,
+// chunks being at least one hop long) and appends its small arrays BEHIND the frame layout's flag words, so that it can clear
+// the frame-form tag there (a recycled buffer must not pass for a frame-form scratch in ddsp_osc_backward).
 size_t chunk_scratch_bytes(int B, int T, int H)
 {
-    const size_t n = (size_t)B * T * H;
-    // chunks are at least one hop long: NC <= T
-    return 2 * align256(n * sizeof(float)) + align256(n * sizeof(double)) + 2 * align256((size_t)B * T * sizeof(int)) +
+    return frame_scratch_bytes(B, T, H) + 2 * align256((size_t)B * T * sizeof(int)) +
            align256((size_t)T * ((size_t)B + 16) * sizeof(int)) + 256;
 }
 
@@ -796,13 +800,14 @@ hipError_t launch_chunked(OscParams p, void *scratch, hipStream_t s)
     Residency res;
     hipError_t e = chunk_geometry<K>(p, &res);
     if (e != hipSuccess) return e;
-    // scratch: w | amp | ctot [B,NC,H] | rlive [B,NC] | perm [NC, RB*64/G] | redo [RB*NC] | flag
+    // scratch: w | amp | ctot [B,NC,H] ... (frame layout's flag words) | rlive [B,NC] | perm [NC, RB*64/G] | redo [RB*NC] | flag
     const size_t n = (size_t)p.B * p.T * p.H;
     char *base = (char *)scratch;
+    p.frame_flag = p.redo_flag;   // where setup_params put the frame layout's flag words
     p.w = (float *)base;
     p.amp = (float *)(base + align256(n * sizeof(float)));
     p.ctot = (double *)(base + 2 * align256(n * sizeof(float)));
-    p.rlive = (int *)((char *)p.ctot + align256((size_t)p.B * p.NC * p.H * sizeof(double)));
+    p.rlive = (int *)(base + frame_scratch_bytes(p.B, p.T, p.H));
     p.perm = (int *)((char *)p.rlive + align256((size_t)p.B * p.NC * sizeof(int)));
     p.redo = (int *)((char *)p.perm + align256((size_t)p.NC * p.RB * (64 >> p.logG) * sizeof(int)));
     p.redo_flag = (int *)((char *)p.redo + align256((size_t)p.RB * p.NC * sizeof(int)));

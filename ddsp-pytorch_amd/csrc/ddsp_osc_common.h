@@ -40,6 +40,7 @@ struct OscParams {
     int *rlive;       // scratch [B,NC]: 1 + highest harmonic slot with a non-zero amplitude anywhere in the row's chunk
     int *perm;        // scratch [NC, RB*64/G]: per chunk index, the batch rows grouped by how many slots they walk (-1 = none)
     int *redo;        // scratch [RB*NC]: wave tasks the fast synth kernel declined
+    int *frame_flag;  // the frame layout's flag words inside this scratch buffer (chunked launches clear the tag there)
     int Lc, NC, RB;   // chunk length in samples, chunks per row, row blocks (64/G rows each)
     int lgR;          // log2(R)
     int nres;         // wavefronts per SIMD the chunks were sized for (turn-taking modulus, <= 3)
@@ -175,6 +176,7 @@ bool setup_params(OscParams &p, void *scratch, int B, int T, int H, int hop, int
 // chunked form (ddsp_osc_chunk.hip)
 bool chunked_eligible(const OscParams &p);
 size_t chunk_scratch_bytes(int B, int T, int H);
+size_t frame_scratch_bytes(int B, int T, int H);
 void pick_chunks(int T, int R, int RB, int cus, int wg_per_cu, int *Lc_out, int *NC_out);
 hipError_t launch_chunked_k(const OscParams &p, void *scratch, hipStream_t s);
 hipError_t chunk_geometry_k(OscParams &p, int *cus, int *wg_per_cu);

@@ -21,18 +21,32 @@ def controls(shape, seed, kind="all_live"):
 @pytest.mark.parametrize("shape,seed,kind", [(syn.CFG2, 1002, "all_live"), (syn.CFG4_PER_GPU, 1004, "musical")])
 def test_oscillator_full_size_properties(shape, seed, kind):
     ctl, x = controls(shape, seed, kind)
+    L = ddsp._lib.lib()
     y, _, _ = ddsp.osc_forward(x["f0"], x["c"], x["a"], shape.hop, shape.sample_rate)
     assert y.shape == (shape.batch, shape.samples) and bool(torch.isfinite(y).all())
     # determinism
     y2, _, _ = ddsp.osc_forward(x["f0"], x["c"], x["a"], shape.hop, shape.sample_rate)
     assert torch.equal(y, y2)
-    # rows are independent: a permuted batch gives the permuted result, bit for bit
+    # rows are independent: a permuted batch gives the permuted result -- bit for bit when every wavefront takes the same walk
+    # (all-live f0: nothing to skip).  With silent harmonics the chunked form groups rows by how many harmonic slots they walk,
+    # and the wavefront at a group boundary walks its rows with the longer group's variant (quotient reuse on or off: the sine
+    # argument then differs by one exact period, v_sin_f32's result by an ulp), so a row's last bits depend on its neighbours.
     perm = torch.randperm(shape.batch, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
     yp, _, _ = ddsp.osc_forward(x["f0"][perm], x["c"][perm], x["a"][perm], shape.hop, shape.sample_rate)
-    assert torch.equal(yp, y[perm])
+    if kind == "all_live":
+        assert torch.equal(yp, y[perm])
+    else:
+        assert float((yp - y[perm]).abs().max()) <= 1e-6
+        assert L.ddsp_osc_set_path(1) == 0   # the frame kernels pick one variant per batch: bit-exact there
+        try:
+            yf, _, _ = ddsp.osc_forward(x["f0"], x["c"], x["a"], shape.hop, shape.sample_rate)
+            yfp, _, _ = ddsp.osc_forward(x["f0"][perm], x["c"][perm], x["a"][perm], shape.hop, shape.sample_rate)
+        finally:
+            L.ddsp_osc_set_path(0)
+        assert torch.equal(yfp, yf[perm])
+        assert float((yf - y).abs().max()) <= 1e-6
     # a sub-batch equals the corresponding rows: bit for bit under the same tiling (same grid-independent arithmetic),
     # and to rounding when the small problem picks fewer harmonics per lane (different summation order over k)
-    L = ddsp._lib.lib()
     ys, _, _ = ddsp.osc_forward(x["f0"][3:10], x["c"][3:10], x["a"][3:10], shape.hop, shape.sample_rate)
     assert float((ys - y[3:10]).abs().max()) <= 2e-6
     assert L.ddsp_osc_set_tiling(13) == 0
@@ -41,7 +55,10 @@ def test_oscillator_full_size_properties(shape, seed, kind):
         yb, _, _ = ddsp.osc_forward(x["f0"][3:10], x["c"][3:10], x["a"][3:10], shape.hop, shape.sample_rate)
     finally:
         L.ddsp_osc_set_tiling(0)
-    assert torch.equal(yb, ya[3:10])
+    if kind == "all_live":
+        assert torch.equal(yb, ya[3:10])
+    else:
+        assert float((yb - ya[3:10]).abs().max()) <= 1e-6
     # linear in the loudness control: y(2a) == 2 y(a) exactly (power-of-two scaling commutes with every rounding)
     yl, _, _ = ddsp.osc_forward(x["f0"], x["c"], 2.0 * x["a"], shape.hop, shape.sample_rate)
     assert torch.equal(yl, 2.0 * y)
