@@ -6,7 +6,8 @@
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch of synthetic controls resident in HBM:
-OscillatorBank.forward (4 kernels) + FilteredNoise.forward accumulated into the same buffer
+OscillatorBank.forward (chunk totals, scan, synth + a repair launch that normally returns at once) + FilteredNoise.forward
+accumulated into the same buffer
 (`harmonics + noise`, decoder.py:132).  Workload = the configuration BASELINE.json's metric is quoted on:
 batch 512 per GPU, 16 kHz, 100 harmonics, hop 128, 4 s clips, 65 noise bands (cfg4's per-GPU shard;
 weak scaling: every rank synthesises its own 512 rows, no collective on the data path).
@@ -59,6 +60,7 @@ from ddsp_pytorch_amd import synthetic as syn  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TLANEOPS = 78.6      # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (= 157.3 TFLOP/s fp32 vector / 2)
+NOMINAL_GHZ = 2.4              # the clock the peaks above are quoted at
 SYNTH_OPS = 11                 # VALU instructions of the synth kernel per harmonic-sample (12 and 10 on alternate samples)
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # fp32 vector peak (FMA = 2 flop)
 SURVEY_FLOPS_PER_HS = 27       # algorithmic flops per harmonic-sample of the whole oscillator path
@@ -102,12 +104,20 @@ def time_config(shape, seed, steps, warmup, f0_kind="all_live", noise_seed=7):
         rec.setdefault(name, []).append(ms)
     ddsp._lib.profile_enable(0)
     assert bool(torch.isfinite(y).all()), "non-finite audio"
+    clock = measure_clock(x, shape)
+    plan = ddsp._lib.osc_plan(shape.batch, shape.frames, shape.n_harmonics, shape.hop, shape.sample_rate)
     del y, x, osc
     torch.cuda.empty_cache()
+    kern = {k: float(np.mean(v)) for k, v in rec.items()}
+    hs = shape.batch * shape.samples * shape.n_harmonics
     return {"workload": f"batch {shape.batch}, {shape.sample_rate} Hz, {shape.n_harmonics} harmonics, hop {shape.hop}, "
                         f"{shape.frames} frames (4 s), {shape.n_noise_filters} noise bands, {f0_kind} f0, in-kernel noise draw",
             "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * el, "samples_per_s": shape.batch * shape.samples / el,
-            "kernel_ms": {k: float(np.mean(v)) for k, v in rec.items()}}
+            "kernel_ms": kern, "clock_ghz": clock, "osc_plan": plan,
+            "synth_harmonic_samples_per_s": hs / (kern["osc_frame_synth"] * 1e-3) if "osc_frame_synth" in kern else None,
+            "totals_harmonic_samples_per_s": hs / (kern["osc_frame_totals"] * 1e-3) if "osc_frame_totals" in kern else None,
+            "synth_Mcycles": kern.get("osc_frame_synth", 0.0) * 1e-3 * clock * 1e3 if clock else None,
+            "totals_Mcycles": kern.get("osc_frame_totals", 0.0) * 1e-3 * clock * 1e3 if clock else None}
 
 
 class Conf:
@@ -139,6 +149,138 @@ def load_pmc():
         if d.get("_meta", {}).get("kernel_sources_sha") == stamp:
             return d, os.path.basename(f)
     return None, None
+
+
+def measure_clock(x, shape, reps=3):
+    """Shader clock (GHz) the oscillator's synth kernel runs at on this box, right now: a wavefront of the production launch
+    stamps the in-kernel shader-clock counter and the 100 MHz wall clock at its start and end (include/ddsp_hip.h:
+    ddsp_osc_clock).  Median of `reps` launches of the same workload, taken right after the timed region."""
+    vals = []
+    for _ in range(reps):
+        _, _, _, scratch = ddsp.osc_forward(x["f0"], x["c"], x["a"], shape.hop, shape.sample_rate, return_scratch=True,
+                                            keep_frame_scratch=False)
+        g = ddsp._lib.osc_clock(scratch, shape.batch, shape.frames, shape.n_harmonics, shape.hop, shape.sample_rate,
+                                torch.cuda.current_stream().cuda_stream)
+        if g > 0:
+            vals.append(g)
+    return float(np.median(vals)) if vals else None
+
+
+def live_callback_ms(calls=100):
+    """The real-time callback (rt/synth.py:40-55 = Decoder.forward_live, decoder.py:139-147) at the reference's default
+    configuration (config/default.py:8-24: 44.1 kHz, hop 512, 180 harmonics, 195 bands, 512-wide MLPs / GRU), 4 frames = 2048
+    samples per call, host arrays in -> host audio out, as ONE hipGraph replay (GraphedLiveDecoder).  Deadline: rt/synth.py:54."""
+    class LiveConf:
+        n_harmonics, n_noise_filters, sample_rate, hop_length = 180, 195, 44100, 512
+        decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 512, 3, 512, 1
+
+    torch.manual_seed(0)
+    rng = np.random.default_rng(3)
+    zn = {"normalized_cents": rng.uniform(0, 1, (1, 4, 1)).astype(np.float32),
+          "loudness": rng.uniform(-1, 1, (1, 4, 1)).astype(np.float32),
+          "f0": rng.uniform(200, 400, (1, 4, 1)).astype(np.float32)}
+    dec = ddsp.Decoder(LiveConf, noise_rng="device").cuda().eval()
+    live = ddsp.GraphedLiveDecoder(dec, frames=4)
+    lat = []
+    for i in range(calls + 10):
+        t0 = time.perf_counter()
+        audio = live.run(zn)
+        if i >= 10:
+            lat.append(time.perf_counter() - t0)
+    assert audio.shape == (2048,) and np.isfinite(audio).all()
+    lat = np.array(lat) * 1e3
+    del live, dec
+    torch.cuda.empty_cache()
+    return {"workload": "Decoder.forward_live, 44.1 kHz, hop 512, 180 harmonics, 195 noise bands, 4 frames = 2048 samples per call "
+                        "(config/default.py:8-24), host in -> host out, one hipGraph replay per call",
+            "calls": calls, "latency_ms_median": float(np.median(lat)), "latency_ms_p99": float(np.percentile(lat, 99)),
+            "deadline_ms": 1e3 * 2048 / 44100, "deadline_source": "rt/synth.py:54 (frames / sample rate)"}
+
+
+def train_step_ms(amp, steps=20, warmup=8, b=32):
+    """BASELINE.json configs[4] per-GPU shape on this ONE GPU (no all-reduce): decoder + HIP synth + reverb + MSS loss + fused
+    Adam, batch 32, 16 kHz, 100 harmonics, 65 bands, 4 s.  amp = 'fp16' is the reference's precision=16 (train/train.py:50:
+    fp16 autocast + GradScaler); 'bf16' has no scaler."""
+    class TrainConf:
+        n_harmonics, n_noise_filters, sample_rate, hop_length = 100, 65, 16000, 128
+        decoder_mlp_units, decoder_mlp_layers, decoder_gru_units, decoder_gru_layers = 512, 3, 512, 1
+
+    frames = 500
+    torch.manual_seed(0)
+    model = ddsp.Decoder(TrainConf, noise_rng="device", seed=0).cuda()
+    loss_fn = ddsp.MSSLoss().cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    rng = np.random.default_rng(2000)
+    batch = {"normalized_cents": torch.from_numpy(rng.uniform(0, 1, (b, frames, 1)).astype(np.float32)).cuda(),
+             "loudness": torch.from_numpy(rng.uniform(-1, 1, (b, frames, 1)).astype(np.float32)).cuda(),
+             "f0": torch.from_numpy(syn.musical_f0(rng, b, frames)).cuda(),
+             "audio": torch.from_numpy((0.1 * rng.standard_normal((b, frames * 128))).astype(np.float32)).cuda()}
+    amp_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}[amp]
+    scaler = torch.amp.GradScaler("cuda") if amp == "fp16" else None
+    for _ in range(warmup):
+        loss, _ = ddsp.train_step(model, loss_fn, opt, batch, amp_dtype=amp_dtype, scaler=scaler)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = ddsp.train_step(model, loss_fn, opt, batch, amp_dtype=amp_dtype, scaler=scaler)
+    issued = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    assert bool(torch.isfinite(loss)), "non-finite loss"
+    del model, loss_fn, opt, batch
+    torch.cuda.empty_cache()
+    return {"workload": f"decoder (4.84 M params) + HIP synth + reverb + MSS loss (6 scales) + fused Adam, batch {b}, 16 kHz, "
+                        f"100 harmonics, 65 bands, 4 s; {amp} autocast GEMMs" + (" + GradScaler (train/train.py:50 precision=16)" if scaler else ""),
+            "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * el / steps, "host_issue_ms_per_step": 1e3 * issued / steps,
+            "samples_per_s": b * frames * 128 * steps / el}
+
+
+def cfg1_figures():
+    """BASELINE.json configs[0]: one 4 s clip, 16 kHz, 60 harmonics, batch 1 -- the reference's CPU-runnable case.  Here: the GPU
+    latency of one OscillatorBank.forward + FilteredNoise call (median of 50, synchronised); the CPU figure: cfg1_cpu."""
+    shape = syn.CFG1
+    ctl = syn.make_controls(shape, 1001, "musical")
+    x = {k: torch.from_numpy(v).cuda() for k, v in ctl.items()}
+    osc = ddsp.OscillatorBank(Conf(shape)).cuda()
+
+    def step(i):
+        y = osc(x)
+        ddsp.noise_forward(x["H"], shape.hop, seed=7, offset=i << 32, out=y, accumulate=True)
+        return y
+
+    for i in range(5):
+        step(i)
+    torch.cuda.synchronize()
+    lat = []
+    for i in range(50):
+        t0 = time.perf_counter()
+        y = step(5 + i)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t0)
+    assert bool(torch.isfinite(y).all())
+    del x, osc, y
+    return {"workload": "batch 1, 16 kHz, 60 harmonics, hop 128, 500 frames (4 s), 65 noise bands, musical f0 (BASELINE.json configs[0])",
+            "gpu_latency_ms_median": 1e3 * float(np.median(lat)), "gpu_samples_per_s": shape.samples / float(np.median(lat)),
+            "osc_plan": ddsp._lib.osc_plan(shape.batch, shape.frames, shape.n_harmonics, shape.hop, shape.sample_rate)}
+
+
+def cfg1_cpu():
+    """configs[0] as BASELINE.json names it -- the reference path on the CPU, no GPU: the torch-op restatement of the same clip on
+    this box's host cores (run last, with the CPU baseline: its thread pool must not compete with the GPU figures' host threads)."""
+    from oracle import torch_restatement as tr
+    shape = syn.CFG1
+    ctl = syn.make_controls(shape, 1001, "musical")
+    f0, c, a, H = (torch.from_numpy(ctl[k]) for k in ("f0", "c", "a", "H"))
+    with torch.no_grad():
+        tr.oscillator_bank(f0, c, a, shape.hop, shape.sample_rate)
+        reps, t0 = 0, time.perf_counter()
+        while reps < 20 and time.perf_counter() - t0 < 3.0:
+            yc = tr.oscillator_bank(f0, c, a, shape.hop, shape.sample_rate)
+            yc += tr.filtered_noise(H, shape.hop)
+            reps += 1
+        cpu_el = (time.perf_counter() - t0) / reps
+    return {"cpu_ms_per_clip": 1e3 * cpu_el, "cpu_samples_per_s": shape.samples / cpu_el, "cpu_threads": torch.get_num_threads(),
+            "cpu_kind": "port (oracle/torch_restatement.py: the reference's torch-op sequence)"}
 
 
 def cpu_baseline(shape, seconds_target=12.0):
@@ -271,7 +413,7 @@ def main():
     ap.add_argument("--harmonics", type=int, default=0, help="override the number of harmonics (tuning experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary BASELINE.json configurations (cfg2, cfg3) timed after the headline at N = 1")
+                    help="skip the secondary figures (cfg1, cfg2, cfg3, musical f0, live callback, training step) timed after the headline at N = 1")
     ap.add_argument("--mode", default="synth", choices=["synth", "train"],
                     help="synth: the headline hot path; train: BASELINE.json configs[4] (decoder + MSS loss + Adam, "
                          "batch 32/GPU, flat RCCL gradient all-reduce) -- a secondary figure, not the metric")
@@ -377,6 +519,9 @@ def main():
     # (clock, thermal, a noisy neighbour on its XCDs) shows up by index instead of hiding inside the MAX
     diag = gather_rows(dist, [1e3 * own_elapsed / args.steps] + [kern_ms.get(k, float("nan")) for k in KERNELS], world, rank)
     del y
+    # the shader clock this box's synth kernel runs at, measured in the kernel right after the timed region (every VALU
+    # fraction below is quoted against the 2.4 GHz peak AND against the peak at this clock: boxes of the pool differ by 10 %)
+    clock = measure_clock(x, shape) if rank == 0 else None
 
     if rank == 0:
         samples_per_step = world * shape.batch * shape.samples
@@ -397,7 +542,7 @@ def main():
             k = [v for n, v in pmc.items() if n.startswith(prefix) and isinstance(v, dict) and "hbm_bytes_per_launch" in v]
             return max(x["hbm_bytes_per_launch"] for x in k) if k else None
 
-        traffic = traffic_of("osc_synth_kernel")
+        traffic = traffic_of("osc_chunk_synth_kernel") or traffic_of("osc_synth_kernel")
         traffic_src = f"profiles/{pmc_name} (FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None
         # the kernel SURVEY §8(d) says can approach the HBM roof: 4 (y) + 4 F / hop (H) bytes per sample (the draw is made
         # in the kernel; the accumulate's read of y is the oscillator's output coming back, not counted as algorithmic)
@@ -405,6 +550,7 @@ def main():
         noise_bps = 4.0 + 4.0 * shape.n_noise_filters / shape.hop
         noise_achieved = launch_samples * noise_bps / (noise_ms * 1e-3) / 1e9
         noise_macs = shape.hop / 2.0 + shape.n_noise_filters          # direct form: truncated convolution + inverse DFT, per sample
+        at_clock = (NOMINAL_GHZ / clock) if clock else None     # peak at this clock = nominal peak x clock / 2.4
         line = {
             "metric": "audio samples/sec/GPU + %HBM-roofline, 16kHz/100-harmonic/batch512",
             "value": samples_per_step * args.steps / elapsed,
@@ -420,6 +566,11 @@ def main():
                        "step": "OscillatorBank.forward + FilteredNoise.forward accumulated (harmonics + noise)",
                        "arithmetic": "fp32 with an fp64 phase accumulator (torch CPU cumsum semantics)"},
             "samples_per_sec_per_gpu": samples_per_step * args.steps / elapsed / world,
+            "clock_ghz": clock, "clock_nominal_ghz": NOMINAL_GHZ,
+            "clock_source": "in-kernel: shader-clock ticks over 100 MHz wall-clock ticks across one synth wavefront (ddsp_osc_clock), "
+                            "median of 3 launches right after the timed region",
+            "osc_plan": ddsp._lib.osc_plan(shape.batch, shape.frames, shape.n_harmonics, shape.hop, shape.sample_rate),
+            "kernel_Mcycles": {k: v * 1e-3 * clock * 1e3 for k, v in kern_ms.items()} if clock else None,
             "roofline": {"bound": "hbm", "kernel": "osc_frame_synth", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": launch_samples * bytes_per_sample,
@@ -428,11 +579,13 @@ def main():
                          "valu": {"harmonic_samples_per_s": hs_per_s, "lane_ops_per_harmonic_sample": SYNTH_OPS,
                                   "achieved_Tlaneops": hs_per_s * SYNTH_OPS / 1e12, "peak_Tlaneops": VALU_PEAK_TLANEOPS,
                                   "frac": hs_per_s * SYNTH_OPS / 1e12 / VALU_PEAK_TLANEOPS,
+                                  "frac_at_clock": hs_per_s * SYNTH_OPS / 1e12 / VALU_PEAK_TLANEOPS * at_clock if at_clock else None,
                                   # SURVEY §8(d)'s own accounting: 27 algorithmic flops per harmonic-sample of the whole path
                                   # against the 157.3 TFLOP/s fp32 vector peak, (a) for this kernel's launch, (b) for the whole step
                                   "survey_flops_per_harmonic_sample": SURVEY_FLOPS_PER_HS, "survey_peak_TFLOPs": FP32_VECTOR_PEAK_TFLOPS,
                                   "survey_achieved_TFLOPs": hs_per_s * SURVEY_FLOPS_PER_HS / 1e12,
                                   "survey_frac": hs_per_s * SURVEY_FLOPS_PER_HS / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                                  "survey_frac_at_clock": hs_per_s * SURVEY_FLOPS_PER_HS / 1e12 / FP32_VECTOR_PEAK_TFLOPS * at_clock if at_clock else None,
                                   "survey_frac_whole_step": (launch_samples * shape.n_harmonics / (elapsed / args.steps))
                                                             * SURVEY_FLOPS_PER_HS / 1e12 / FP32_VECTOR_PEAK_TFLOPS},
                          "noise_frame": {"bound": "hbm", "kernel": "noise_frame", "achieved": noise_achieved, "peak": HBM_PEAK_GBS,
@@ -444,7 +597,8 @@ def main():
                                          "valu": {"mac_per_sample": noise_macs,
                                                   "achieved_Tlaneops": launch_samples * noise_macs / (noise_ms * 1e-3) / 1e12,
                                                   "peak_Tlaneops": VALU_PEAK_TLANEOPS,
-                                                  "frac": launch_samples * noise_macs / (noise_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS}}},
+                                                  "frac": launch_samples * noise_macs / (noise_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS,
+                                                  "frac_at_clock": launch_samples * noise_macs / (noise_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS * at_clock if at_clock else None}}},
             "kernel_ms": kern_ms,
             "per_rank_ms": [float(v) for v in diag[:, 0]],
             "per_rank_kernel_ms": {k: [float(v) for v in diag[:, 1 + j]] for j, k in enumerate(KERNELS)},
@@ -457,10 +611,17 @@ def main():
             # 10 steps each.  `value` above is the metric's configuration only.
             del x, osc
             torch.cuda.empty_cache()
-            line["configs"] = {"note": "secondary: timed after the headline region, 10 steps each, not part of `value`",
-                               "cfg2": time_config(syn.CFG2, 1002, 10, 2), "cfg3": time_config(syn.CFG3, 1003, 10, 2)}
+            line["configs"] = {"note": "secondary figures: every one timed AFTER the headline's timed region, none is part of `value`",
+                               "cfg1": cfg1_figures(),
+                               "cfg2": time_config(syn.CFG2, 1002, 10, 2), "cfg3": time_config(syn.CFG3, 1003, 10, 2),
+                               "musical": time_config(syn.CFG4_PER_GPU, 1004, 10, 2, f0_kind="musical"),
+                               "live_callback": live_callback_ms(),
+                               "train_step": {"note": "BASELINE.json configs[4] per-GPU shape on this one GPU (no all-reduce)",
+                                              "fp16_gradscaler": train_step_ms("fp16"), "bf16": train_step_ms("bf16")}}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(shape)
+            if "configs" in line:
+                line["configs"]["cfg1"].update(cfg1_cpu())
         print(json.dumps(line), file=RESULT, flush=True)
     if dist is not None:
         dist.barrier()

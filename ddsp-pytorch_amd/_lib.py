@@ -57,6 +57,8 @@ def lib():
     L.ddsp_osc_forward_ex.argtypes = [vp] * 8 + [i32] * 5 + [ctypes.c_uint, vp]
     L.ddsp_osc_set_path.restype = i32
     L.ddsp_osc_set_path.argtypes = [i32]
+    L.ddsp_osc_clock.restype = i32
+    L.ddsp_osc_clock.argtypes = [vp, i32, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_double), vp]
     L.ddsp_osc_plan.restype = i32
     L.ddsp_osc_plan.argtypes = [i32] * 5 + [ctypes.POINTER(i32), i32]
     L.ddsp_noise_forward.restype = i32
@@ -151,7 +153,7 @@ def lib():
     return L
 
 
-EXPORTS = ("ddsp_hip_abi_version", "ddsp_test_hooks_enabled", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_osc_forward_ex", "ddsp_osc_set_path", "ddsp_osc_plan", "ddsp_noise_forward", "ddsp_noise_forward_counter",
+EXPORTS = ("ddsp_hip_abi_version", "ddsp_test_hooks_enabled", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_osc_forward_ex", "ddsp_osc_set_path", "ddsp_osc_plan", "ddsp_osc_clock", "ddsp_noise_forward", "ddsp_noise_forward_counter",
            "ddsp_osc_backward_scratch_bytes", "ddsp_osc_backward", "ddsp_noise_backward", "ddsp_noise_backward_counter",
            "ddsp_osc_set_tiling", "ddsp_noise_set_generic", "ddsp_profile_enable", "ddsp_profile_read",
            "ddsp_gru_scratch_bytes", "ddsp_gru_max_batch", "ddsp_gru_forward", "ddsp_gru_backward", "ddsp_gru_forward_bf16", "ddsp_gru_backward_bf16", "ddsp_gru_status", "ddsp_gru_set_mode", "ddsp_gru_set_fault_step",
@@ -194,3 +196,10 @@ def osc_plan(B: int, T: int, H: int, hop: int, sample_rate: int) -> dict:
     keys = ("harmonics_per_lane", "lanes_per_row", "chunked", "chunk_samples", "chunks_per_row", "row_blocks",
             "compute_units", "workgroups_per_unit")
     return dict(zip(keys, list(out)))
+
+
+def osc_clock(scratch, B: int, T: int, H: int, hop: int, sample_rate: int, stream: int = 0) -> float:
+    """Shader clock (GHz) of the synth kernel of the last ddsp_osc_forward on `scratch` (a torch uint8 tensor); synchronises."""
+    ghz = ctypes.c_double(0.0)
+    check(lib().ddsp_osc_clock(scratch.data_ptr(), B, T, H, hop, sample_rate, ctypes.byref(ghz), stream or None), "ddsp_osc_clock")
+    return float(ghz.value)

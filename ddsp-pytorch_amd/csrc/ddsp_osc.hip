@@ -407,6 +407,8 @@ __global__ void __launch_bounds__(256, (SKIP && K <= 13) ? 3 : 1) osc_synth_kern
 {
     if (VARIANT == VAR_EXACT && !p.force_exact && *p.redo_flag == 0) return;
     if (VARIANT == VAR_FAST && POW2 && p.R >= 8 && (p.redo_flag[1] != 0) != SKIP) return;
+    const bool probe = VARIANT == VAR_FAST && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+    if (probe) clock_stamp(p.redo_flag, 0);
     const int G = 1 << p.logG;
     const long gid = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     const int j = threadIdx.x & (G - 1);
@@ -476,6 +478,7 @@ __global__ void __launch_bounds__(256, (SKIP && K <= 13) ? 3 : 1) osc_synth_kern
         else if (SKIP && mlive <= KH) DDSP_WALK2(KH, 2);
         else DDSP_WALK2(K, 1);
 #undef DDSP_WALK2
+        if (probe) clock_stamp(p.redo_flag, 1);
     } else {
         float lp[K];
 #pragma unroll
@@ -657,6 +660,21 @@ extern "C" int ddsp_osc_plan(int B, int T, int H, int hop, int sample_rate, int 
         if (e != hipSuccess) return (int)e;
         out[2] = 1; out[3] = p.Lc; out[4] = p.NC; out[5] = p.RB; out[6] = cus; out[7] = wgs;
     }
+    return 0;
+}
+
+extern "C" int ddsp_osc_clock(const void *scratch, int B, int T, int H, int hop, int sample_rate, double *ghz, void *stream)
+{
+    if (!scratch || !ghz || B <= 0 || T <= 0 || H <= 0 || hop <= 0 || sample_rate <= 0) return DDSP_EINVAL;
+    OscParams p = {};
+    if (!setup_params(p, const_cast<void *>(scratch), B, T, H, hop, sample_rate)) return DDSP_ERANGE;
+    const int *flag = p.redo_flag;
+    if (g_path.load(std::memory_order_relaxed) == 0 && chunked_eligible(p)) flag = chunk_flag_words(p);
+    unsigned long long w[4] = {0, 0, 0, 0};
+    hipError_t e = hipMemcpyAsync(w, flag + 16, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    *ghz = (w[3] > w[1] && w[2] > w[0]) ? (double)(w[2] - w[0]) / (double)(w[3] - w[1]) * 0.1 : 0.0;
     return 0;
 }
 

@@ -571,6 +571,7 @@ __global__ void __launch_bounds__(256, (!EXACT && K <= 13) ? 3 : 1) osc_chunk_sy
 #ifdef DDSP_CHUNK_STAMPS
         const long stamp0 = wall_clock64();
 #endif
+        if (!EXACT && wt == 0 && (threadIdx.x & 63) == 0) clock_stamp(p.redo_flag, 0);
         Task k = decode_task(p, wt);
         {   // the rows of this chunk index in the order of pass 2 (rows that stop at the same slot share a wavefront)
             const int idx = k.rb * (64 >> p.logG) + ((threadIdx.x & 63) >> p.logG);
@@ -670,6 +671,7 @@ __global__ void __launch_bounds__(256, (!EXACT && K <= 13) ? 3 : 1) osc_chunk_sy
             if ((threadIdx.x & 63) == 0) {
                 p.redo[wt] = redo ? 1 : 0;
                 if (redo) atomicOr(p.redo_flag, 1);
+                if (wt == 0) clock_stamp(p.redo_flag, 1);
             }
 #ifdef DDSP_CHUNK_STAMPS
             if ((threadIdx.x & 63) == 0 && wt < 16384) {
@@ -794,12 +796,8 @@ hipError_t chunk_geometry(OscParams &p, Residency *res_out)
     return hipSuccess;
 }
 
-template <int K>
-hipError_t launch_chunked(OscParams p, void *scratch, hipStream_t s)
+void carve_chunk_scratch(OscParams &p, void *scratch)
 {
-    Residency res;
-    hipError_t e = chunk_geometry<K>(p, &res);
-    if (e != hipSuccess) return e;
     // scratch: w | amp | ctot [B,NC,H] ... (frame layout's flag words) | rlive [B,NC] | perm [NC, RB*64/G] | redo [RB*NC] | flag
     const size_t n = (size_t)p.B * p.T * p.H;
     char *base = (char *)scratch;
@@ -811,6 +809,15 @@ hipError_t launch_chunked(OscParams p, void *scratch, hipStream_t s)
     p.perm = (int *)((char *)p.rlive + align256((size_t)p.B * p.NC * sizeof(int)));
     p.redo = (int *)((char *)p.perm + align256((size_t)p.NC * p.RB * (64 >> p.logG) * sizeof(int)));
     p.redo_flag = (int *)((char *)p.redo + align256((size_t)p.RB * p.NC * sizeof(int)));
+}
+
+template <int K>
+hipError_t launch_chunked(OscParams p, void *scratch, hipStream_t s)
+{
+    Residency res;
+    hipError_t e = chunk_geometry<K>(p, &res);
+    if (e != hipSuccess) return e;
+    carve_chunk_scratch(p, scratch);
 
     const long tasks = (long)p.RB * p.NC;
     const unsigned grid = (unsigned)((tasks + 3) / 4);
@@ -843,6 +850,15 @@ hipError_t chunk_geometry_k(OscParams &p, int *cus, int *wg_per_cu)
     *cus = res.cus;
     *wg_per_cu = res.wg_per_cu;
     return e;
+}
+
+// the flag words of a chunked launch inside `scratch` (p from setup_params on that scratch)
+const int *chunk_flag_words(OscParams p)
+{
+    int cus = 0, wgs = 0;
+    if (chunk_geometry_k(p, &cus, &wgs) != hipSuccess) return p.redo_flag;
+    carve_chunk_scratch(p, (void *)p.w);
+    return p.redo_flag;
 }
 
 hipError_t launch_chunked_k(const OscParams &p, void *scratch, hipStream_t s)

@@ -20,7 +20,8 @@ struct OscParams {
     float *w, *amp;   // scratch [B,T,H]: written by the totals kernel (row t), read by the synth kernels
     double *loc;      // scratch [B,T,H]: exclusive prefix of the frame totals inside the frame's superblock
     double *sup;      // scratch [B,NSB,H]: superblock totals, then (in place) their exclusive scan along t
-    int *redo_flag;   // scratch: set by the FAST synth kernel when a wavefront needs the EXACT one
+    int *redo_flag;   // scratch: set by the FAST synth kernel when a wavefront needs the EXACT one; 64 bytes further on:
+                      // four 64-bit words {shader clock, 100 MHz clock} at the start and at the end of one synth wavefront (ddsp_osc_clock)
     const float *live_in;
     float *live_out;
     float *dbg_phi;
@@ -59,6 +60,15 @@ __device__ __forceinline__ unsigned xcd_block(unsigned bid, unsigned nblocks)
     const unsigned per = nblocks >> 3;
     if (per == 0 || bid >= (per << 3)) return bid;          // the ragged tail keeps its position
     return (bid & 7u) * per + (bid >> 3);
+}
+
+// Shader-clock probe: one wavefront of the synth kernel stamps {s_memtime, s_memrealtime} when it starts and when it ends;
+// (delta shader ticks) / (delta 100 MHz ticks) * 0.1 = the GHz the kernel actually ran at (ddsp_osc_clock reads it back).
+__device__ __forceinline__ void clock_stamp(int *redo_flag, int which)
+{
+    unsigned long long *w = reinterpret_cast<unsigned long long *>(redo_flag + 16) + 2 * which;
+    w[0] = __builtin_amdgcn_s_memtime();
+    w[1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ---- cross-lane helpers -------------------------------------------------------------------
@@ -180,5 +190,6 @@ size_t frame_scratch_bytes(int B, int T, int H);
 void pick_chunks(int T, int R, int RB, int cus, int wg_per_cu, int *Lc_out, int *NC_out);
 hipError_t launch_chunked_k(const OscParams &p, void *scratch, hipStream_t s);
 hipError_t chunk_geometry_k(OscParams &p, int *cus, int *wg_per_cu);
+const int *chunk_flag_words(OscParams p);
 
 }  // namespace ddsp_osc

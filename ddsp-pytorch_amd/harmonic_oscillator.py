@@ -30,10 +30,13 @@ OSC_KEEP_FRAME_SCRATCH = 1  # include/ddsp_hip.h: DDSP_OSC_KEEP_FRAME_SCRATCH
 
 
 def osc_forward(f0, c, a, hop: int, sample_rate: int, live_in=None, want_live_out=False, debug_phases=False,
-                return_scratch=False):
+                return_scratch=False, keep_frame_scratch=None):
     """Raw launcher over the C ABI (include/ddsp_hip.h: ddsp_osc_forward_ex). Returns (y, live_out, phi[, scratch]).
 
-    `return_scratch=True` (the autograd path) asks for the frame-form scratch ddsp_osc_backward re-walks."""
+    `return_scratch=True` (the autograd path) asks for the frame-form scratch ddsp_osc_backward re-walks, unless
+    `keep_frame_scratch=False` (diagnostics: ddsp_osc_clock on the production launch's scratch)."""
+    if keep_frame_scratch is None:
+        keep_frame_scratch = return_scratch
     _check_inputs(f0, c, a)
     f0 = f0.detach().contiguous().float()
     c = c.detach().contiguous().float()
@@ -52,7 +55,7 @@ def osc_forward(f0, c, a, hop: int, sample_rate: int, live_in=None, want_live_ou
         stream = torch.cuda.current_stream().cuda_stream
         rc = L.ddsp_osc_forward_ex(f0.data_ptr(), c.data_ptr(), a.data_ptr(), y.data_ptr(), scratch.data_ptr(),
                                    _dev_ptr(live_in), _dev_ptr(live_out), _dev_ptr(phi), B, T, H, hop, sample_rate,
-                                   OSC_KEEP_FRAME_SCRATCH if return_scratch else 0, stream)
+                                   OSC_KEEP_FRAME_SCRATCH if keep_frame_scratch else 0, stream)
     _lib.check(rc, "ddsp_osc_forward_ex")
     return (y, live_out, phi, scratch) if return_scratch else (y, live_out, phi)
 

@@ -129,6 +129,10 @@ int ddsp_osc_set_path(int path);
  * lane, [1] lanes per row group, [2] 1 = chunked form, then its [3] chunk length in samples, [4] chunks per row,
  * [5] row blocks, [6] compute units and [7] resident workgroups per unit the chunk length was sized for. */
 int ddsp_osc_plan(int B, int T, int H, int hop, int sample_rate, int *out, int cap);
+/* Diagnostic, SYNCHRONISES `stream`: the shader clock (GHz) one wavefront of the synth kernel of the LAST ddsp_osc_forward
+ * on `scratch` (same B, T, H, hop, sample_rate, same hooks) ran at: in-kernel shader-clock ticks over 100 MHz wall-clock
+ * ticks between that wavefront's start and end.  ghz is a HOST pointer; 0.0 if the kernel did not run.  Not for launch paths. */
+int ddsp_osc_clock(const void *scratch, int B, int T, int H, int hop, int sample_rate, double *ghz, void *stream);
 
 /* Test / tuning hook (process-global, read once per launch): bit 0 forces the generic one-frame-per-workgroup noise kernels
  * (any hop) instead of the batched ones (hop % 8 == 0, tile fits LDS); bit 1 keeps the direct (time-domain) forms where the

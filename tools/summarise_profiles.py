@@ -15,7 +15,7 @@ import sys
 
 src, rnd = sys.argv[1], sys.argv[2]
 dst = src
-KEYS = ("osc_synth_kernel", "osc_totals_kernel", "osc_supscan_kernel", "noise_wave_kernel", "noise_fft_kernel", "noise_batched_kernel", "noise_frame_kernel")
+KEYS = ("osc_chunk_synth_kernel", "osc_chunk_totals_kernel", "osc_chunk_scan_kernel", "osc_synth_kernel", "osc_totals_kernel", "osc_supscan_kernel", "noise_wave_kernel", "noise_fft_kernel", "noise_batched_kernel", "noise_frame_kernel")
 
 
 def short(name):
