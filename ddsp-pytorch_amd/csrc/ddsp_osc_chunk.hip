@@ -144,6 +144,7 @@ __device__ __forceinline__ void walk_synth(const OscParams &p, ChunkState<K> &st
     const int G = 1 << p.logG, per = 32 >> p.logG;
     float lam, dlam;
     segment_lambda(p, n_beg, clamp0, lam, dlam);
+    float mal = 1.0f - lam;   // w0
     float *ycol = ystage + threadIdx.x;
     const float *yblk = ystage + (threadIdx.x & ~(G - 1));
     static_assert(QMODE == 0 || (QMODE == 1 && NS == 1) || (QMODE == 2 && NS == 2), "quotient reuse: across iterations or inside a pair");
@@ -156,11 +157,12 @@ __device__ __forceinline__ void walk_synth(const OscParams &p, ChunkState<K> &st
     take_turn(slot, p.nres, p.turn_shift);
     for (int n = nb; n < nb + RUN; n += NS) {
         float w0[NS], w1[NS];
+        w1[0] = lam;
+        w0[0] = mal;
 #pragma unroll
-        for (int e = 0; e < NS; ++e) {
-            w1[e] = lam;
-            w0[e] = 1.0f - lam;
-            lam += dlam;
+        for (int e = 1; e < NS; ++e) {   // both weights advance by exactly 1/hop (dyadic rationals: no rounding)
+            w1[e] = w1[e - 1] + dlam;
+            w0[e] = w0[e - 1] - dlam;
         }
         float v[NS][KL];
         DDSP_STAGE_END();
@@ -254,6 +256,8 @@ __device__ __forceinline__ void walk_synth(const OscParams &p, ChunkState<K> &st
         const int ia = i_abs + (n - n_beg);
 #pragma unroll
         for (int e = 0; e < NS; ++e) ycol[((ia + e) & 31) * kRow] = s0[e] + s1[e];
+        lam = w1[NS - 1] + dlam;     // (advanced after their last use: no copies)
+        mal = w0[NS - 1] - dlam;
     }
         const int ia_end = i_abs + (nb + RUN - n_beg);   // absolute index one past the run
         if ((ia_end & 31) == 0) {
@@ -331,11 +335,13 @@ __device__ __forceinline__ void walk_totals(const OscParams &p, double (&acc)[K]
 {
     float lam, dlam;
     segment_lambda(p, n_beg, clamp0, lam, dlam);
+    float mal = 1.0f - lam;
     for (int nb = n_beg; nb < n_end; nb += 16) {
     take_turn(slot, p.nres, p.turn_shift - 2);
     for (int n = nb; n < nb + 16; ++n) {
-        const float w1 = lam, w0 = 1.0f - lam;
+        const float w1 = lam, w0 = mal;
         lam += dlam;
+        mal -= dlam;
         float v[K];
         DDSP_STAGE_END();
 #pragma unroll
@@ -447,16 +453,16 @@ __global__ void __launch_bounds__(256, K <= 13 ? 3 : 1) osc_chunk_totals_kernel(
 // of the others take one chunk index each: perm[c][.] = the batch rows ordered by the class of their highest
 // audible slot in chunk c (all K slots first, then 3/4, 1/2, 1/4, 1/8), so that the rows a synth wavefront walks together
 // stop at the same slot; entries past B are -1.
-__global__ void __launch_bounds__(256) osc_chunk_scan_kernel(OscParams p, int nscan_blocks, int Q)
+__global__ void __launch_bounds__(512) osc_chunk_scan_kernel(OscParams p, int nscan_blocks, int Q)
 {
-    __shared__ double seg_tot[4][64];
+    __shared__ double seg_tot[8][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *p.redo_flag = 0;
         p.frame_flag[2] = 0;   // not a frame-form scratch (ddsp_osc_backward checks kFrameScratchTag here)
     }
     if ((int)blockIdx.x < nscan_blocks) {
-        // 64 columns per workgroup, coalesced along h; the chunk range is cut into Q <= 4 segments, one per wavefront: first the
+        // 64 columns per workgroup, coalesced along h; the chunk range is cut into Q <= 8 segments, one per wavefront: first the
         // segment totals (independent loads), then each segment's exclusive scan starting from the totals before it
         const long ncol = (long)p.B * p.H;
         const long idx = (long)blockIdx.x * 64 + lane;
@@ -514,7 +520,7 @@ __global__ void __launch_bounds__(256) osc_chunk_scan_kernel(OscParams p, int ns
         }
         return;
     }
-    const long wv = (long)(blockIdx.x - nscan_blocks) * 4 + q;
+    const long wv = (long)(blockIdx.x - nscan_blocks) * 8 + q;
     const int c = (int)wv;
     if (c >= p.NC) return;
     const int Bpad = p.RB * (64 >> p.logG);
@@ -826,8 +832,8 @@ hipError_t launch_chunked(OscParams p, void *scratch, hipStream_t s)
     ddsp_prof::end(slot, s);
     slot = ddsp_prof::begin(ddsp_prof::SCAN, s);
     const long nscan_blocks = ((long)p.B * p.H + 63) / 64;
-    const int Q = p.NC > 64 ? 4 : (p.NC > 32 ? 2 : 1);   // <= 32 chunks per wavefront up to 128 chunks: the register form
-    hipLaunchKernelGGL(osc_chunk_scan_kernel, dim3((unsigned)(nscan_blocks + (p.NC + 3) / 4)), dim3(256), 0, s, p, (int)nscan_blocks, Q);
+    const int Q = p.NC > 128 ? 8 : (p.NC > 64 ? 4 : (p.NC > 32 ? 2 : 1));   // <= 32 chunks per wavefront up to 256 chunks: the register form
+    hipLaunchKernelGGL(osc_chunk_scan_kernel, dim3((unsigned)(nscan_blocks + (p.NC + 7) / 8)), dim3(512), 0, s, p, (int)nscan_blocks, Q);
     ddsp_prof::end(slot, s);
     slot = ddsp_prof::begin(ddsp_prof::SYNTH, s);
     hipLaunchKernelGGL((osc_chunk_synth_kernel<K, false>), dim3(grid), dim3(256), sizeof(float) * 32 * kRow, s, p);

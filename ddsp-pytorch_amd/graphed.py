@@ -186,6 +186,7 @@ class GraphedTrainStep:
         self.noises = [m for m in model.modules() if isinstance(m, FilteredNoise) and m.rng == "device"]
         # (the modules see their counter only inside this object's steps; eager calls keep the host-side offset)
         self.counters = [torch.tensor([m._offset], dtype=torch.int64, device=dev) for m in self.noises]
+        self._mirror = [int(m._offset) for m in self.noises]    # what each device counter holds (host-side knowledge)
         self.loss = None
         self.nbytes = sum(p.numel() * p.element_size() for p in self.params)
         self._capture(dev, warmup)
@@ -271,14 +272,21 @@ class GraphedTrainStep:
             for k, v in batch.items():
                 if torch.is_tensor(v):
                     self.batch[k].copy_(v, non_blocking=True)
+        # eager calls of the same model between graphed steps (validation, an eager train_step) advance only the modules'
+        # host-side offsets: bring the device counters up to them first, so that this replay does not redraw that noise
+        for i, (m, c) in enumerate(zip(self.noises, self.counters)):
+            if int(m._offset) != self._mirror[i]:
+                c.fill_(int(m._offset))                 # an async fill from a host integer, outside the graph
+                self._mirror[i] = int(m._offset)
         self._graph.replay()
         if self.world > 1:
             self._reduce()
             self._graph_update.replay()
-        # keep the modules' host-side offsets in step with the device counters: an eager call of the same model between or
-        # after graphed steps (validation, an eager train_step) continues the stream instead of replaying its start
-        for m, d in zip(self.noises, self._draws):
-            m._offset += d
+        # ... and keep the host-side offsets in step with the device counters, so that an eager call after graphed steps
+        # continues the stream instead of replaying its start
+        for i, (m, d) in enumerate(zip(self.noises, self._draws)):
+            self._mirror[i] += d
+            m._offset = self._mirror[i]
         return self.loss, self.nbytes
 
     __call__ = step

@@ -105,6 +105,16 @@ def gru_backward(dy, dhT, w_hh, h0, y, gates, hn, scratch_out: list | None = Non
                     hn[lo:hi].data_ptr(), d_gi[lo:hi].data_ptr(), d_gh[lo:hi].data_ptr(), dh0[lo:hi].data_ptr(),
                     scratch.data_ptr(), hi - lo, T, Hd)
             rc = launch(*args, 1 if io16 else 0, stream) if lowp else launch(*args, stream)
+            if rc == -2 and io16:
+                # (DDSP_ERANGE: sequences of >= 65536 steps take the fp32 backward kernels, which write fp32 gradients --
+                # redo the slice with fp32 outputs and cast)
+                f_gi = torch.empty_like(gates[lo:hi], dtype=torch.float32)
+                f_gh = torch.empty_like(f_gi)
+                args32 = args[:7] + (f_gi.data_ptr(), f_gh.data_ptr()) + args[9:]
+                rc = launch(*args32, 0, stream)
+                _lib.check(rc, "ddsp_gru_backward")
+                d_gi[lo:hi].copy_(f_gi)
+                d_gh[lo:hi].copy_(f_gh)
             _lib.check(rc, "ddsp_gru_backward")
             if scratch_out is not None:
                 scratch_out.append(scratch)

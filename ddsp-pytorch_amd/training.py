@@ -159,13 +159,15 @@ class SpectralLoss(nn.Module):
 
     def fused_scale(self, x: torch.Tensor):
         """(n_fft, hop, window, alpha, eps) when this scale can run as ONE HIP kernel on `x` (ddsp_mss_scale), else None."""
+        # (ddsp_mss_scale takes a NORMAL positive eps; a denormal eps stays on the library-FFT path, eps = 0 -- legal in the reference,
+        # loss/mss_loss.py:16 -- on the stock torch formulation at the end of forward)
         if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0 and x.shape[1] > self.n_fft // 2 and self.hop > 0
-                and _lib.lib().ddsp_mss_scale_supported(self.n_fft)):
+                and self.eps >= 1.1754944e-38 and _lib.lib().ddsp_mss_scale_supported(self.n_fft)):
             return (self.n_fft, self.hop, self.window.to(device=x.device, dtype=torch.float32).contiguous(), self.alpha, self.eps)
         return None
 
     def forward(self, x_pred, x_true):
-        if x_pred.is_cuda and x_pred.dtype == torch.float32:
+        if x_pred.is_cuda and x_pred.dtype == torch.float32 and self.eps > 0.0:
             scale = self.fused_scale(x_pred)
             if scale is not None and x_true.shape == x_pred.shape and not x_true.requires_grad:
                 return _FusedScales.apply(x_pred, x_true.float(), (scale,))

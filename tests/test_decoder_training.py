@@ -750,3 +750,128 @@ def test_graphed_train_step_equals_eager_steps(amp_dtype):
     with torch.no_grad():
         h = {"H": torch.rand(3, 40, 9, device="cuda")}
         assert torch.equal(m_g.noise(h), m_e.noise(h))
+    # ... and the other way round: that eager call advanced only the module's host-side offset; the next graphed step must pick
+    # it up (device counter written before the replay), not redraw the noise the eager call used
+    assert m_g.noise._offset == m_e.noise._offset == 5 * m_g.noise.draws(3, 40)
+    loss_e, _ = ddsp.train_step(m_e, l_e, o_e, batch(4), amp_dtype=amp_dtype)
+    loss_g, _ = graphed.step(batch(4))
+    assert int(graphed.counters[0].item()) == 6 * m_g.noise.draws(3, 40) == m_e.noise._offset == m_g.noise._offset
+    assert abs(loss_e.item() - loss_g.item()) <= tol * abs(loss_e.item())
+    with torch.no_grad():
+        assert torch.equal(m_g.noise(h), m_e.noise(h))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("amp_dtype", [torch.bfloat16, torch.float16])
+def test_linear_block_under_autocast_equals_its_separate_parts(amp_dtype):
+    """decoder._LinearBlock (Linear -> LayerNorm -> LeakyReLU as one autograd node; the LayerNorm backward's column sums ARE the
+    Linear's bias gradient) against the same 16-bit GEMMs + the stand-alone fused LayerNorm node + dense.colsum: y, gx, gw, gb
+    within 2 ulp of the 16-bit type."""
+    from ddsp_pytorch_amd import decoder as dec
+    from ddsp_pytorch_amd import dense
+    torch.manual_seed(12)
+    rows, n_in, D = 96, 64, 256          # (the fused LayerNorm pass takes widths that are multiples of 256)
+    x = torch.randn(rows, n_in, device="cuda", requires_grad=True)
+    w = (torch.randn(D, n_in, device="cuda") / n_in ** 0.5).requires_grad_()
+    b = (0.1 * torch.randn(D, device="cuda")).requires_grad_()
+    gamma = (1 + 0.1 * torch.randn(D, device="cuda")).requires_grad_()
+    beta = (0.1 * torch.randn(D, device="cuda")).requires_grad_()
+    gy = torch.randn(rows, D, device="cuda")
+    with torch.autocast("cuda", dtype=amp_dtype):
+        y = dec._LinearBlock.apply(x, w, b, gamma, beta, 1e-5, 0.01)
+    assert y.dtype == amp_dtype
+    gx, gw, gb, gg, gbeta = torch.autograd.grad(y, (x, w, b, gamma, beta), gy.to(y.dtype))
+    # the parts: the same 16-bit GEMM, then the stand-alone LayerNorm + LeakyReLU node, bias gradient by a column sum
+    x2, w2, b2 = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    g2, be2 = gamma.detach().clone().requires_grad_(), beta.detach().clone().requires_grad_()
+    with torch.autocast("cuda", dtype=amp_dtype):
+        h = torch.nn.functional.linear(x2, w2, b2)
+        y2 = dec._LayerNormLeakyReLU.apply(h, g2, be2, 1e-5, 0.01)
+    rx, rw, rb, rg, rbeta = torch.autograd.grad(y2, (x2, w2, b2, g2, be2), gy.to(y2.dtype))
+    ulp = 2.0 ** -7 if amp_dtype == torch.bfloat16 else 2.0 ** -10
+
+    def close(a, r, name, k=2.0):
+        scale = max(float(r.float().abs().max()), 1e-6)
+        assert float((a.float() - r.float()).abs().max()) <= k * ulp * scale, (name, float((a.float() - r.float()).abs().max()), scale)
+
+    close(y, y2, "y")
+    close(gx, rx, "gx", 4.0)
+    close(gw, rw, "gw", 4.0)
+    close(gb, rb, "gb", 4.0)      # bias gradient from the LayerNorm backward's column sums vs autograd's own reduction
+    close(gg, rg, "dgamma", 4.0)
+    close(gbeta, rbeta, "dbeta", 4.0)
+
+
+@pytest.mark.gpu
+def test_spectral_loss_with_zero_or_denormal_eps_does_not_raise():
+    """eps = 0 is legal in the reference ((s + eps).log2(), loss/mss_loss.py:16); the HIP loss kernels want a positive eps (the
+    one-kernel scale a normal one), so SpectralLoss falls back -- denormal: HIP framing + library FFT + fused L1; zero: the stock
+    torch formulation -- instead of raising."""
+    torch.manual_seed(4)
+    x = (0.3 * torch.randn(2, 4096, device="cuda")).requires_grad_()
+    t = 0.3 * torch.randn(2, 4096, device="cuda")
+    from ddsp_pytorch_amd.training import SpectralLoss
+    loss0 = SpectralLoss(256, eps=0.0).cuda()
+    assert loss0.fused_scale(x) is None and SpectralLoss(256, eps=1e-7).cuda().fused_scale(x) is not None
+    val = loss0(x, t)
+    (g,) = torch.autograd.grad(val, x)
+    assert bool(torch.isfinite(val)) and bool(torch.isfinite(g).all())
+    tiny = SpectralLoss(256, eps=1e-42).cuda()           # denormal: not the one-kernel scale, still a HIP path
+    assert tiny.fused_scale(x) is None
+    vt = tiny(x, t)
+    assert abs(float(vt) - float(val)) <= 1e-5 * abs(float(val))
+    # fp64 torch.stft formulation of the same loss
+    xd, td = x.detach().double().cpu(), t.double().cpu()
+    win = torch.hann_window(256, dtype=torch.float64)
+
+    def power(s):
+        return torch.stft(s, 256, hop_length=64, window=win, center=True, pad_mode="reflect", return_complex=True).abs() ** 2
+
+    sp, st = power(xd), power(td)
+    ref = (sp - st).abs().mean() + (torch.log2(st) - torch.log2(sp)).abs().mean()
+    assert abs(float(val) - float(ref)) <= 1e-4 * abs(float(ref))
+
+
+@pytest.mark.gpu
+def test_spectral_scale_gradient_on_the_case_the_fuzz_sweep_flagged():
+    """Case 70 of `python tests/fuzz_parity.py 120 777 training` (fixture g18, re-derived by tools/make_fuzz_case.py): n_fft 2048,
+    overlap 0 (hop 2048), 2 rows of 1081 samples -- ONE frame, mostly reflection padding, weight 0.3 on the log term.  In round 3
+    the one-kernel scale missed the fp64 gradient by 3.5e-3 of its norm here against a conditioning yardstick of 2.5e-4; the cause
+    was a running-product twiddle in the 2048-point transform (exact table since commit d59cda0).
+
+    The criterion of the sweep, pinned on this named case: the HIP gradient is within max(1e-3, 8 x yardstick) of the fp64 one
+    (relative L2), where the yardstick is the larger of (a) torch's own fp32 formulation's distance from fp64 and (b) the fp64
+    gradient's own movement under an fp32-epsilon perturbation of the input -- the L1 terms' gradient is discontinuous where a
+    bin of the prediction ties with the target's, and a single-frame case has few bins to average over.  1e-3 is the floor
+    because near-empty bins put torch fp32 itself between 2e-6 and 1e-3 on single-frame cases (tools/microbench/mss_case.py)."""
+    from conftest import load_golden
+    from ddsp_pytorch_amd.training import SpectralLoss
+    fx = load_golden("g18_mss_fuzz_case")
+    n_fft, overlap, alpha = int(fx["n_fft"]), float(fx["overlap"]), float(fx["alpha"])
+    x_true, x_pred = torch.from_numpy(fx["x_true"]), torch.from_numpy(fx["x_pred"])
+    assert (n_fft, overlap, tuple(x_pred.shape)) == (2048, 0.0, (2, 1081))
+    sl = SpectralLoss(n_fft, alpha=alpha, overlap=overlap)
+    xp = x_pred.double().requires_grad_(True)
+    ref = sl.double()(xp, x_true.double())
+    ref.backward()
+    sl_gpu = SpectralLoss(n_fft, alpha=alpha, overlap=overlap).cuda()
+    xg = x_pred.cuda().requires_grad_(True)
+    assert sl_gpu.fused_scale(xg) is not None                       # the one-kernel scale is what runs
+    got = sl_gpu(xg, x_true.cuda())
+    got.backward()
+    e_loss = abs(got.item() - ref.item()) / abs(ref.item())
+    e_l2 = float((xg.grad.cpu().double() - xp.grad).norm() / xp.grad.norm())
+    # yardstick (a): torch's fp32 formulation on the CPU
+    x32 = x_pred.clone().requires_grad_(True)
+    SpectralLoss(n_fft, alpha=alpha, overlap=overlap)(x32, x_true).backward()
+    y_a = float((x32.grad.double() - xp.grad).norm() / xp.grad.norm())
+    # yardstick (b): conditioning -- an fp32-epsilon perturbation of the input, evaluated in fp64 (fixed generator)
+    g = torch.Generator().manual_seed(70)
+    xq = (x_pred.double() + 6e-8 * 0.3 * torch.randn(x_pred.shape, generator=g, dtype=torch.float64)).requires_grad_(True)
+    sl.double()(xq, x_true.double()).backward()
+    y_b = float((xq.grad - xp.grad).norm() / xp.grad.norm())
+    yard = max(y_a, y_b)
+    print(f"loss {e_loss:.2e}  gradient L2 {e_l2:.2e}  yardstick fp32-torch {y_a:.2e} conditioning {y_b:.2e}")
+    assert e_loss <= 2e-5
+    assert e_l2 <= max(1e-3, 8.0 * yard), (e_l2, yard)
+    assert e_l2 <= 2e-3          # and in absolute terms: well below the 3.5e-3 the sweep flagged in round 3

@@ -340,6 +340,33 @@ def test_gru_bf16_matrix_core_variant_tracks_fp32(B, T, hd, with_h0):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,T,hd,with_h0", [(4, 30, 64, True), (32, 60, 512, False), (9, 17, 200, True)])
+def test_gru_bf16_backward_16bit_outputs_equal_the_cast_of_the_fp32_outputs(B, T, hd, with_h0):
+    """io_type 1 of ddsp_gru_backward_bf16 (d_gi / d_gh stored as bf16 for the autocast GEMMs that consume them) against the same
+    kernel's fp32 stores: the 16-bit tensors are the round-to-nearest-even cast of the fp32 ones (<= 1 bf16 ulp), dh0 identical."""
+    torch.manual_seed(B * 3 + hd)
+    gi = torch.randn(B, T, 3 * hd, device="cuda")
+    w = torch.randn(3 * hd, hd, device="cuda") * (1.0 / hd ** 0.5)
+    b = torch.randn(3 * hd, device="cuda") * 0.1
+    h0 = torch.randn(B, hd, device="cuda").tanh() if with_h0 else None
+    dy = torch.randn(B, T, hd, device="cuda")
+    dhT = torch.randn(B, hd, device="cuda")
+    y, _, gates, hn = gru_mod.gru_forward(gi, w, b, h0, save=True, lowp=True)
+    f_gi, f_gh, f_dh0 = gru_mod.gru_backward(dy, dhT, w, h0, y, gates, hn, lowp=True)
+    used = []
+    h_gi, h_gh, h_dh0 = gru_mod.gru_backward(dy, dhT, w, h0, y, gates, hn, scratch_out=used, lowp=True, io16=True)
+    assert all(gru_mod.gru_status(s) == 0 for s in used)
+    assert h_gi.dtype == torch.bfloat16 and h_gh.dtype == torch.bfloat16 and f_gi.dtype == torch.float32
+    assert torch.equal(h_dh0, f_dh0)
+    for half, full, name in ((h_gi, f_gi, "d_gi"), (h_gh, f_gh, "d_gh")):
+        want = full.to(torch.bfloat16)
+        exact = float((half == want).float().mean())
+        # one bf16 ulp = 2^-8 relative: the kernel rounds the same fp32 value, so (almost) every element is the exact cast
+        assert exact >= 0.999, (name, exact)
+        assert float((half.float() - full).abs().max()) <= 2.0 ** -7 * float(full.abs().max()), name
+
+
+@pytest.mark.gpu
 def test_gru_module_under_autocast_uses_the_bf16_variant_and_trains():
     torch.manual_seed(3)
     ref, mine = _pair(24, 128, 77)
