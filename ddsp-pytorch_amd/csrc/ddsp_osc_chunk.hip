@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(512) osc_chunk_scan_kernel(OscParams p, int ns
         }
         return;
     }
-    const long wv = (long)(blockIdx.x - nscan_blocks) * 8 + q;
+    const long wv = (long)(blockIdx.x - nscan_blocks) * (blockDim.x >> 6) + q;
     const int c = (int)wv;
     if (c >= p.NC) return;
     const int Bpad = p.RB * (64 >> p.logG);
@@ -833,7 +833,7 @@ hipError_t launch_chunked(OscParams p, void *scratch, hipStream_t s)
     slot = ddsp_prof::begin(ddsp_prof::SCAN, s);
     const long nscan_blocks = ((long)p.B * p.H + 63) / 64;
     const int Q = p.NC > 128 ? 8 : (p.NC > 64 ? 4 : (p.NC > 32 ? 2 : 1));   // <= 32 chunks per wavefront up to 256 chunks: the register form
-    hipLaunchKernelGGL(osc_chunk_scan_kernel, dim3((unsigned)(nscan_blocks + (p.NC + 7) / 8)), dim3(512), 0, s, p, (int)nscan_blocks, Q);
+    hipLaunchKernelGGL(osc_chunk_scan_kernel, dim3((unsigned)(nscan_blocks + (p.NC + Q - 1) / Q)), dim3(64 * Q), 0, s, p, (int)nscan_blocks, Q);   // one wavefront per segment
     ddsp_prof::end(slot, s);
     slot = ddsp_prof::begin(ddsp_prof::SYNTH, s);
     hipLaunchKernelGGL((osc_chunk_synth_kernel<K, false>), dim3(grid), dim3(256), sizeof(float) * 32 * kRow, s, p);
