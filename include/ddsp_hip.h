@@ -48,9 +48,10 @@ int ddsp_hip_abi_version(void);
 int ddsp_test_hooks_enabled(void);
 
 /*
- * Bytes of device scratch ddsp_osc_forward needs for a [B,T,H] problem:
- * frame-rate increments fp32 [B,T,H] + normalised amplitudes fp32 [B,T,H] +
- * frame-start phase accumulators fp64 [B,T,H]  (16*B*T*H bytes, 256-byte aligned parts).
+ * Bytes of device scratch ddsp_osc_forward needs for a [B,T,H] problem (any hop): frame-rate increments fp32 [B,T,H] +
+ * normalised amplitudes fp32 [B,T,H] + an fp64 region of [B,T,H] (chunk totals, or frame-start phases + their superblock
+ * totals) + a few int32 arrays of at most B*T entries (16*B*T*H bytes + ~2*B*(T+3)/4*H + 12*B*T + 4*T*(B+16) + flag words;
+ * 256-byte aligned parts).
  */
 size_t ddsp_osc_scratch_bytes(int B, int T, int H);
 

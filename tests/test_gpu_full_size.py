@@ -167,7 +167,7 @@ def test_graphed_synth_offline_and_live():
 
 def test_cfg3_whole_workload():
     """BASELINE.json configs[2] as written: batch 512, 48 kHz, hop 512, 375 frames (4 s), 200 harmonics, 257 noise bands --
-    the K=25/G=8 oscillator tiling, 4x longer phase drift than the 1 s fixture G4, 16-frames-per-workgroup noise tiles.
+    the K=13/G=16 oscillator tiling (chunked form, 8 000-sample chunks), 4x longer phase drift than the 1 s fixture G4, 16-frames-per-workgroup noise tiles.
     The oracle does three whole rows in seconds; the other 509 rows are covered by size-independent properties."""
     shape = syn.CFG3
     ctl, x = controls(shape, 1003)
