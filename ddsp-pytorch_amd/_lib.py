@@ -107,6 +107,10 @@ def lib():
     L.ddsp_scaled_sigmoid_forward.argtypes = [vp, vp, ctypes.c_long, vp]
     L.ddsp_scaled_sigmoid_backward.restype = i32
     L.ddsp_scaled_sigmoid_backward.argtypes = [vp, vp, vp, ctypes.c_long, vp]
+    L.ddsp_heads_sigmoid_forward.restype = i32
+    L.ddsp_heads_sigmoid_forward.argtypes = [vp] * 4 + [ctypes.c_long, i32, i32, i32, i32, vp]
+    L.ddsp_heads_sigmoid_backward.restype = i32
+    L.ddsp_heads_sigmoid_backward.argtypes = [vp] * 5 + [ctypes.c_long, i32, i32, i32, i32, vp]
     L.ddsp_ln_lrelu_scratch_bytes.restype = ctypes.c_size_t
     L.ddsp_ln_lrelu_scratch_bytes.argtypes = [i32]
     L.ddsp_ln_lrelu_forward.restype = i32
@@ -157,7 +161,7 @@ EXPORTS = ("ddsp_hip_abi_version", "ddsp_test_hooks_enabled", "ddsp_osc_scratch_
            "ddsp_osc_backward_scratch_bytes", "ddsp_osc_backward", "ddsp_noise_backward", "ddsp_noise_backward_counter",
            "ddsp_osc_set_tiling", "ddsp_noise_set_generic", "ddsp_profile_enable", "ddsp_profile_read",
            "ddsp_gru_scratch_bytes", "ddsp_gru_max_batch", "ddsp_gru_forward", "ddsp_gru_backward", "ddsp_gru_forward_bf16", "ddsp_gru_backward_bf16", "ddsp_gru_status", "ddsp_gru_set_mode", "ddsp_gru_set_fault_step",
-           "ddsp_spectral_loss_scratch_bytes", "ddsp_spectral_loss", "ddsp_scaled_sigmoid_forward", "ddsp_scaled_sigmoid_backward",
+           "ddsp_spectral_loss_scratch_bytes", "ddsp_spectral_loss", "ddsp_scaled_sigmoid_forward", "ddsp_scaled_sigmoid_backward", "ddsp_heads_sigmoid_forward", "ddsp_heads_sigmoid_backward",
            "ddsp_ln_lrelu_scratch_bytes", "ddsp_ln_lrelu_forward", "ddsp_ln_lrelu_backward", "ddsp_ln_lrelu_forward_16", "ddsp_ln_lrelu_backward_16", "ddsp_outer_ln_lrelu_scratch_bytes", "ddsp_outer_ln_lrelu_forward", "ddsp_outer_ln_lrelu_backward",
            "ddsp_colsum_scratch_bytes", "ddsp_colsum", "ddsp_stft_frames", "ddsp_stft_frames_backward", "ddsp_mss_scale_scratch_bytes", "ddsp_mss_scale_supported", "ddsp_mss_scale", "ddsp_reverb_impulse", "ddsp_reverb_impulse_backward", "ddsp_spectral_mul", "ddsp_spectral_mul_backward",
            "ddsp_reverb_live_scratch_bytes", "ddsp_reverb_live")

@@ -55,6 +55,83 @@ extern "C" int ddsp_scaled_sigmoid_backward(const float *x, const float *grad_y,
     return (int)hipGetLastError();
 }
 
+// ---- the three control heads as one epilogue (decoder.py:96-100, :110-116) ------------------------------------------
+// The controller ends in three Linear layers on the same activations (harmonic amplitudes, loudness, filter magnitudes),
+// each followed by modified_sigmoid.  Run as ONE GEMM on the concatenated weights, their outputs arrive as one
+// [rows, n0+n1+n2] matrix (fp32, or the 16-bit autocast type): this pass applies the sigmoid and writes the three controls
+// as separate dense fp32 tensors (what the synthesis kernels take); the backward reads the three upstream gradients and
+// writes one gradient matrix in the GEMM's type.
+namespace {
+
+template <typename T> __device__ __forceinline__ float head_ld(const T *p, long i) { return (float)p[i]; }
+template <typename T> __device__ __forceinline__ void head_st(T *p, long i, float v) { p[i] = (T)v; }
+
+template <typename T>
+__global__ void __launch_bounds__(256) heads_fwd_kernel(const T *__restrict__ x, float *__restrict__ o0, float *__restrict__ o1,
+                                                        float *__restrict__ o2, long rows, int n0, int n1, int n2)
+{
+    const int N = n0 + n1 + n2;
+    const long total = rows * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / N;
+        const int c = (int)(i - r * N);
+        const float s = 1.0f / (1.0f + expf(-head_ld(x, i)));
+        const float y = 2.0f * powf(s, kExponent) + kFloor;
+        if (c < n0) o0[r * n0 + c] = y;
+        else if (c < n0 + n1) o1[r * n1 + (c - n0)] = y;
+        else o2[r * n2 + (c - n0 - n1)] = y;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) heads_bwd_kernel(const T *__restrict__ x, const float *__restrict__ g0, const float *__restrict__ g1,
+                                                        const float *__restrict__ g2, T *__restrict__ gx, long rows, int n0, int n1, int n2)
+{
+    const int N = n0 + n1 + n2;
+    const long total = rows * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / N;
+        const int c = (int)(i - r * N);
+        const float g = c < n0 ? g0[r * n0 + c] : (c < n0 + n1 ? g1[r * n1 + (c - n0)] : g2[r * n2 + (c - n0 - n1)]);
+        const float s = 1.0f / (1.0f + expf(-head_ld(x, i)));
+        head_st(gx, i, g * (2.0f * kExponent * powf(s, kExponent) * (1.0f - s)));
+    }
+}
+
+}  // namespace
+
+extern "C" int ddsp_heads_sigmoid_forward(const void *x, float *out0, float *out1, float *out2, long rows, int n0, int n1, int n2,
+                                          int io_type, void *stream)
+{
+    if (rows == 0) return 0;
+    if (!x || !out0 || !out1 || !out2 || rows < 0 || n0 <= 0 || n1 <= 0 || n2 <= 0) return DDSP_EINVAL;
+    const unsigned grid = grid_for(rows * (n0 + n1 + n2));
+    hipStream_t s = (hipStream_t)stream;
+    switch (io_type) {
+        case 0: hipLaunchKernelGGL(heads_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float *)x, out0, out1, out2, rows, n0, n1, n2); break;
+        case 1: hipLaunchKernelGGL(heads_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16 *)x, out0, out1, out2, rows, n0, n1, n2); break;
+        case 2: hipLaunchKernelGGL(heads_fwd_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16 *)x, out0, out1, out2, rows, n0, n1, n2); break;
+        default: return DDSP_EINVAL;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int ddsp_heads_sigmoid_backward(const void *x, const float *g0, const float *g1, const float *g2, void *grad_x, long rows,
+                                           int n0, int n1, int n2, int io_type, void *stream)
+{
+    if (rows == 0) return 0;
+    if (!x || !g0 || !g1 || !g2 || !grad_x || rows < 0 || n0 <= 0 || n1 <= 0 || n2 <= 0) return DDSP_EINVAL;
+    const unsigned grid = grid_for(rows * (n0 + n1 + n2));
+    hipStream_t s = (hipStream_t)stream;
+    switch (io_type) {
+        case 0: hipLaunchKernelGGL(heads_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float *)x, g0, g1, g2, (float *)grad_x, rows, n0, n1, n2); break;
+        case 1: hipLaunchKernelGGL(heads_bwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16 *)x, g0, g1, g2, (__bf16 *)grad_x, rows, n0, n1, n2); break;
+        case 2: hipLaunchKernelGGL(heads_bwd_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16 *)x, g0, g1, g2, (_Float16 *)grad_x, rows, n0, n1, n2); break;
+        default: return DDSP_EINVAL;
+    }
+    return (int)hipGetLastError();
+}
+
 // ---- LayerNorm + LeakyReLU of the MLP blocks (decoder.py:9-39: Linear -> LayerNorm -> LeakyReLU) ------------------
 // One pass forward (y = lrelu(gamma * (x - mean) * rstd + beta); mean and rstd kept per row) and one pass backward
 // (dx, plus per-workgroup partial sums of d gamma / d beta finished by a second small kernel: deterministic) instead of

@@ -370,8 +370,10 @@ __global__ void __launch_bounds__(256) osc_totals_kernel(OscParams p)
             dst[(long)f * p.H] = run;
             run += v;
         }
-        p.sup[((long)b * p.NSB + sb) * p.H + h] = run;
+        // (one superblock per row: its exclusive prefix is 0 and the scan launch is skipped)
+        p.sup[((long)b * p.NSB + sb) * p.H + h] = p.NSB == 1 ? 0.0 : run;
     }
+    if (p.NSB == 1 && blockIdx.x == 0 && threadIdx.x == 0) p.redo_flag[2] = kFrameScratchTag;   // (otherwise the scan kernel tags)
 }
 
 // ---- pass 2: exclusive scan of the superblock totals along t (B*H independent columns, NSB steps) -------
@@ -516,8 +518,12 @@ hipError_t launch_frames(const OscParams &p, hipStream_t s)
         if (e != hipSuccess) return e;
     }
     const dim3 tgrid((unsigned)(p.B * p.NSB)), blk(256);
-    hipError_t me = hipMemsetAsync(p.redo_flag, 0, 2 * sizeof(int), s);  // [0] redo-exact, [1] batch has silent harmonics
-    if (me != hipSuccess) return me;
+    if (!live && !p.force_exact) {
+        // [0] redo-exact, [1] batch has silent harmonics: only the FAST synth kernels read them (live / debug calls go straight
+        // to the EXACT kernel: no reset, one launch fewer in the real-time callback)
+        hipError_t me = hipMemsetAsync(p.redo_flag, 0, 2 * sizeof(int), s);
+        if (me != hipSuccess) return me;
+    }
     int slot = ddsp_prof::begin(ddsp_prof::TOTALS, s);
     if (p.live_in) {
         hipLaunchKernelGGL((osc_totals_kernel<K, true, false>), tgrid, blk, lds, s, p);
@@ -527,9 +533,11 @@ hipError_t launch_frames(const OscParams &p, hipStream_t s)
         hipLaunchKernelGGL((osc_totals_kernel<K, false, false>), tgrid, blk, lds, s, p);
     }
     ddsp_prof::end(slot, s);
-    slot = ddsp_prof::begin(ddsp_prof::SCAN, s);
-    hipLaunchKernelGGL(osc_supscan_kernel, dim3((unsigned)(((long)p.B * p.H + 255) / 256)), dim3(256), 0, s, p);
-    ddsp_prof::end(slot, s);
+    if (p.NSB > 1) {
+        slot = ddsp_prof::begin(ddsp_prof::SCAN, s);
+        hipLaunchKernelGGL(osc_supscan_kernel, dim3((unsigned)(((long)p.B * p.H + 255) / 256)), dim3(256), 0, s, p);
+        ddsp_prof::end(slot, s);
+    }
     slot = ddsp_prof::begin(ddsp_prof::SYNTH, s);
     if (!live && !p.force_exact) {
         if (p.pow2) {

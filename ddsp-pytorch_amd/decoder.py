@@ -256,6 +256,62 @@ def scaled_sigmoid(x: torch.Tensor) -> torch.Tensor:
     return 2.0 * torch.sigmoid(x).pow(2.3026) + 1e-7
 
 
+class _Heads(torch.autograd.Function):
+    """The three control heads (decoder.py:96-100: dense_harmonic, dense_loudness, dense_filter, each followed by modified_sigmoid
+    :110-116) as ONE GEMM on the concatenated weights + ONE epilogue pass each way (include/ddsp_hip.h: ddsp_heads_sigmoid_*)
+    instead of three GEMMs (one of them 1 wide) and three sigmoid passes forward, and nine GEMMs / reductions backward.  The
+    parameters stay three separate tensors (checkpoint compatibility): their gradients are row slices of one weight gradient."""
+
+    _IO = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+    @staticmethod
+    def forward(ctx, z, w0, b0, w1, b1, w2, b2):
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else z.dtype
+        if dt not in _Heads._IO:
+            dt = torch.float32
+        zc = z.to(dt).contiguous()
+        W = torch.cat([dense._cast(w, dt) for w in (w0, w1, w2)], 0)
+        b = torch.cat([dense._cast(v, dt) for v in (b0, b1, b2)], 0)
+        with torch.autocast("cuda", enabled=False):
+            h = F.linear(zc, W, b).contiguous()
+        ns = (w0.shape[0], w1.shape[0], w2.shape[0])
+        rows = h.numel() // sum(ns)
+        outs = [torch.empty(z.shape[:-1] + (n,), device=z.device, dtype=torch.float32) for n in ns]
+        with torch.cuda.device(z.device):
+            _lib.check(_lib.lib().ddsp_heads_sigmoid_forward(h.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), rows,
+                                                             ns[0], ns[1], ns[2], _Heads._IO[dt], torch.cuda.current_stream().cuda_stream),
+                       "ddsp_heads_sigmoid_forward")
+        ctx.save_for_backward(zc, W, h)
+        ctx.ns, ctx.in_dtype, ctx.param_dtypes = ns, z.dtype, (w0.dtype, b0.dtype)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        zc, W, h = ctx.saved_tensors
+        ns = ctx.ns
+        rows = h.numel() // sum(ns)
+        gs = [(torch.zeros(h.shape[:-1] + (n,), device=h.device) if g is None else g.contiguous().float()) for g, n in zip((g0, g1, g2), ns)]
+        gh = torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            _lib.check(_lib.lib().ddsp_heads_sigmoid_backward(h.data_ptr(), gs[0].data_ptr(), gs[1].data_ptr(), gs[2].data_ptr(), gh.data_ptr(), rows,
+                                                              ns[0], ns[1], ns[2], _Heads._IO[h.dtype], torch.cuda.current_stream().cuda_stream),
+                       "ddsp_heads_sigmoid_backward")
+        wdt, bdt = ctx.param_dtypes
+        gz = gw = gb = None
+        with torch.autocast("cuda", enabled=False):
+            g2d = gh.reshape(-1, gh.shape[-1])
+            if ctx.needs_input_grad[0]:
+                gz = (g2d @ W).view(zc.shape).to(ctx.in_dtype)
+            if any(ctx.needs_input_grad[1::2]):
+                gw = dense.weight_grad(g2d, zc.reshape(-1, zc.shape[-1])).to(wdt)
+            if any(ctx.needs_input_grad[2::2]):
+                gb = dense.colsum(g2d).to(bdt)
+        o1, o2 = ns[0], ns[0] + ns[1]
+        cut = lambda t: (None, None, None) if t is None else (t[:o1], t[o1:o2], t[o2:])   # noqa: E731
+        (gw0, gw1, gw2), (gb0, gb1, gb2) = cut(gw), cut(gb)
+        return gz, gw0, gb0, gw1, gb1, gw2, gb2
+
+
 class Controller(nn.Module):
     """f0 / loudness features -> control dict {f0, c, a, H, hidden} (decoder.py:41-108)."""
 
@@ -280,10 +336,14 @@ class Controller(nn.Module):
             # cat widening both stacks to fp32 and the next Linear narrowing all three again (the Linear computes in 16 bit anyway)
             z = z.to(z_pitch.dtype)
         z = _run_stack(self.mlp_gru, torch.cat((z, z_pitch, z_loud), dim=-1))
-        def head(layer):
-            return scaled_sigmoid(dense.linear(z, layer.weight, layer.bias))
-
-        controls = dict(f0=batch['f0'], c=head(self.dense_harmonic), hidden=state, H=head(self.dense_filter), a=head(self.dense_loudness))
+        if z.is_cuda and z.dtype in _Heads._IO:
+            c, a, H = _Heads.apply(z, self.dense_harmonic.weight, self.dense_harmonic.bias, self.dense_loudness.weight,
+                                   self.dense_loudness.bias, self.dense_filter.weight, self.dense_filter.bias)
+        else:
+            def head(layer):
+                return scaled_sigmoid(dense.linear(z, layer.weight, layer.bias))
+            c, a, H = head(self.dense_harmonic), head(self.dense_loudness), head(self.dense_filter)
+        controls = dict(f0=batch['f0'], c=c, hidden=state, H=H, a=a)
         if hidden is not None:
             return controls, hidden    # the INPUT state, as the reference returns it
         return controls

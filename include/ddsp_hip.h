@@ -301,6 +301,13 @@ int ddsp_spectral_loss(const float *pred_ri, const float *true_ri, float *grad_r
  */
 int ddsp_scaled_sigmoid_forward(const float *x, float *y, long n, void *stream);
 int ddsp_scaled_sigmoid_backward(const float *x, const float *grad_y, float *grad_x, long n, void *stream);
+/* The controller's three heads (decoder.py:96-100) after ONE GEMM on their concatenated weights: modified_sigmoid of x
+ * [rows, n0+n1+n2] (io_type 0 fp32, 1 bf16, 2 fp16: the GEMM's output type) written as three dense fp32 tensors [rows,n0],
+ * [rows,n1], [rows,n2]; the backward takes their three fp32 gradients and writes grad_x in x's type. */
+int ddsp_heads_sigmoid_forward(const void *x, float *out0, float *out1, float *out2, long rows, int n0, int n1, int n2,
+                               int io_type, void *stream);
+int ddsp_heads_sigmoid_backward(const void *x, const float *g0, const float *g1, const float *g2, void *grad_x, long rows,
+                                int n0, int n1, int n2, int io_type, void *stream);
 
 /*
  * LayerNorm followed by LeakyReLU over rows of D = 256, 512, 768 or 1024 fp32 elements (the MLP blocks of

@@ -875,3 +875,35 @@ def test_spectral_scale_gradient_on_the_case_the_fuzz_sweep_flagged():
     assert e_loss <= 2e-5
     assert e_l2 <= max(1e-3, 8.0 * yard), (e_l2, yard)
     assert e_l2 <= 2e-3          # and in absolute terms: well below the 3.5e-3 the sweep flagged in round 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("amp_dtype", [None, torch.bfloat16, torch.float16])
+def test_fused_heads_equal_the_three_separate_heads(amp_dtype):
+    """decoder._Heads (the three control heads of decoder.py:96-100 as one GEMM on the concatenated weights + one modified_sigmoid
+    epilogue each way) against the reference formulation head by head -- Linear, then 2 sigmoid(x)^2.3026 + 1e-7 (:110-116) --
+    values and every gradient (activations, three weights, three biases)."""
+    from ddsp_pytorch_amd import decoder as dec
+    torch.manual_seed(31)
+    B, T, width, ns = 3, 17, 64, (10, 1, 7)
+    z = torch.randn(B, T, width, device="cuda", requires_grad=True)
+    ws = [(torch.randn(n, width, device="cuda") / width ** 0.5).requires_grad_() for n in ns]
+    bs = [(0.1 * torch.randn(n, device="cuda")).requires_grad_() for n in ns]
+    gs = [torch.randn(B, T, n, device="cuda") for n in ns]
+    with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
+        outs = dec._Heads.apply(z, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2])
+    assert all(o.dtype == torch.float32 and o.is_contiguous() and o.shape == (B, T, n) for o, n in zip(outs, ns))
+    grads = torch.autograd.grad(outs, [z] + ws + bs, gs)
+    z2 = z.detach().clone().requires_grad_()
+    ws2 = [w.detach().clone().requires_grad_() for w in ws]
+    bs2 = [b.detach().clone().requires_grad_() for b in bs]
+    with torch.autocast("cuda", dtype=amp_dtype or torch.bfloat16, enabled=amp_dtype is not None):
+        ref = [2.0 * torch.sigmoid(torch.nn.functional.linear(z2, w, b).float()).pow(2.3026) + 1e-7 for w, b in zip(ws2, bs2)]
+    rgrads = torch.autograd.grad(ref, [z2] + ws2 + bs2, gs)
+    tol = 2e-6 if amp_dtype is None else (3e-2 if amp_dtype == torch.bfloat16 else 4e-3)
+    for o, r, n in zip(outs, ref, ns):
+        assert float((o - r).abs().max()) <= tol * max(1.0, float(r.abs().max())), n
+    names = ["z"] + [f"w{i}" for i in range(3)] + [f"b{i}" for i in range(3)]
+    for g, r, name in zip(grads, rgrads, names):
+        assert g.shape == r.shape and g.dtype == r.dtype, name
+        assert float((g.float() - r.float()).abs().max()) <= 4 * tol * max(1e-3, float(r.float().abs().max())), (name, float((g.float() - r.float()).abs().max()))

@@ -17,3 +17,9 @@ def test_random_shapes_match_the_oracle(seed):
 def test_random_shapes_of_the_loss_side_kernels_match_torch(seed):
     """40 random cases per seed: one-kernel spectral-loss scales (value + gradient, any overlap), the framing pair, column sums."""
     assert fuzz_parity.sweep_training_kernels(40, seed, verbose=False) == 0
+
+
+@pytest.mark.parametrize("seed", [404])
+def test_random_shapes_of_the_chunked_oscillator_match_the_oracle(seed):
+    bad, worst = fuzz_parity.sweep_chunked(60, seed, verbose=False)
+    assert bad == 0 and worst <= 1e-5

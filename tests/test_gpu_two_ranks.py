@@ -89,7 +89,10 @@ def test_data_parallel_replicas_lock_step_and_equal_single_process(rank_outputs)
         d_ref, d_got = ref[k] - init[k], sd0[k] - init[k]
         scale = float(d_ref.abs().max())
         moved += scale > 0
-        assert float((d_got - d_ref).abs().max()) <= 2e-4 * scale + 1e-9, k
+        # (Adam divides by sqrt(v): where a gradient entry is close to zero, fp32 summation order -- two half batches all-reduced
+        # against one full batch, split-K weight gradients of different heights -- decides its update; 1e-3 of the largest update
+        # still catches a wrong average or a missing shard by three orders of magnitude)
+        assert float((d_got - d_ref).abs().max()) <= 1e-3 * scale + 1e-9, k
     assert moved >= 30                                             # every trainable tensor received a gradient
     # the ranks' mean loss is the batch loss (equal shards)
     l0 = torch.load(rank_outputs / "loss0.pt", weights_only=True)
