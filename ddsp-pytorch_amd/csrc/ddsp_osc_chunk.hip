@@ -733,7 +733,9 @@ void pick_chunks(int T, int R, int RB, int cus, int wg_per_cu, int *Lc_out, int 
     double best = 1e300;
     int bestLc = (int)N, bestNC = 1;
     int lastLc = -1;
-    for (int nc = 1; nc <= T; ++nc) {   // chunks are at least one hop long
+    // (more chunks per row than ~16 workgroups per compute unit never pay: bounds the search for long clips of few rows)
+    const long nc_cap = (64L * cus) / (RB > 0 ? RB : 1) + 2;
+    for (int nc = 1; nc <= T && nc <= nc_cap; ++nc) {   // chunks are at least one hop long
         long Lc = (N + nc - 1) / nc;
         Lc = (Lc + 31) & ~31L;
         if (Lc < R) Lc = R;

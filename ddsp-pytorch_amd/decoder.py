@@ -256,6 +256,9 @@ def scaled_sigmoid(x: torch.Tensor) -> torch.Tensor:
     return 2.0 * torch.sigmoid(x).pow(2.3026) + 1e-7
 
 
+FUSED_HEADS = True   # (tools/microbench/heads_ab.py flips it for the before / after figure)
+
+
 class _Heads(torch.autograd.Function):
     """The three control heads (decoder.py:96-100: dense_harmonic, dense_loudness, dense_filter, each followed by modified_sigmoid
     :110-116) as ONE GEMM on the concatenated weights + ONE epilogue pass each way (include/ddsp_hip.h: ddsp_heads_sigmoid_*)
@@ -336,7 +339,7 @@ class Controller(nn.Module):
             # cat widening both stacks to fp32 and the next Linear narrowing all three again (the Linear computes in 16 bit anyway)
             z = z.to(z_pitch.dtype)
         z = _run_stack(self.mlp_gru, torch.cat((z, z_pitch, z_loud), dim=-1))
-        if z.is_cuda and z.dtype in _Heads._IO:
+        if FUSED_HEADS and z.is_cuda and z.dtype in _Heads._IO:
             c, a, H = _Heads.apply(z, self.dense_harmonic.weight, self.dense_harmonic.bias, self.dense_loudness.weight,
                                    self.dense_loudness.bias, self.dense_filter.weight, self.dense_filter.bias)
         else:
