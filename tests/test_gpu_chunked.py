@@ -183,3 +183,56 @@ def test_backward_refuses_a_chunked_scratch(lib):
     assert rc == 0
     gc2, ga2 = ddsp.harmonic_oscillator.osc_backward(g, f0, c, a, scratch2, hop, sr)
     assert bool(torch.isnan(gc2).all()) and bool(torch.isnan(ga2).all())
+
+
+def test_chunked_form_is_graph_capturable_and_stream_safe(lib):
+    """The chunked launches (occupancy query cached per device, four kernels, no host synchronisation) captured into a hipGraph on
+    a side stream and replayed -- on live input buffers -- equal the eager result bit for bit; and a launch from a worker thread
+    on its own stream (the JACK callback's situation, rt/synth.py:50-52) does too."""
+    import threading
+    B, T, H, hop, sr = 16, 40, 100, 128, 16000
+    f0, c, a = (dev(v) for v in controls(B, T, H, sr, "musical", 77))
+    force_chunked(lib, 13, B, T, H, hop, sr)
+    eager, _, _ = ddsp.osc_forward(f0, c, a, hop, sr)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            ddsp.osc_forward(f0, c, a, hop, sr)            # warm-up outside the capture (allocator, occupancy cache)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y_static, _, _ = ddsp.osc_forward(f0, c, a, hop, sr)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y_static, eager)
+    a.mul_(2.0)                                             # graphs read the live input buffers
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y_static, 2.0 * eager)
+    a.mul_(0.5)
+    out = {}
+
+    def worker():
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            out["y"] = ddsp.osc_forward(f0, c, a, hop, sr)[0]
+        s.synchronize()
+
+    th = threading.Thread(target=worker)
+    th.start()
+    th.join()
+    assert torch.equal(out["y"], eager)
+
+
+def test_clock_probe_reads_a_plausible_shader_clock(lib):
+    B, T, H, hop, sr = 64, 125, 100, 128, 16000
+    f0, c, a = (dev(v) for v in controls(B, T, H, sr, "all_live", 5))
+    force_chunked(lib, 13, B, T, H, hop, sr)
+    _, _, _, scratch = ddsp.osc_forward(f0, c, a, hop, sr, return_scratch=True, keep_frame_scratch=False)
+    ghz = ddsp._lib.osc_clock(scratch, B, T, H, hop, sr)
+    assert 0.5 <= ghz <= 3.0, ghz           # MI355X: up to 2.4 GHz
+    ddsp._lib.check(lib.ddsp_osc_set_path(1), "ddsp_osc_set_path")      # the frame kernels stamp the same words
+    _, _, _, scratch = ddsp.osc_forward(f0, c, a, hop, sr, return_scratch=True, keep_frame_scratch=False)
+    ghz2 = ddsp._lib.osc_clock(scratch, B, T, H, hop, sr)
+    assert 0.5 <= ghz2 <= 3.0, ghz2
