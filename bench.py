@@ -235,6 +235,14 @@ def train_step_ms(amp, steps=20, warmup=8, b=32):
             "samples_per_s": b * frames * 128 * steps / el}
 
 
+def train_step_figures():
+    """Both precisions, after a throw-away pass: the first training run of a process pays one-time costs (GEMM heuristics, allocator
+    growth after the synthesis configurations' large buffers were released) that are not the step's."""
+    train_step_ms("bf16", steps=5, warmup=5)
+    return {"note": "BASELINE.json configs[4] per-GPU shape on this one GPU (no all-reduce); a throw-away pass runs first",
+            "fp16_gradscaler": train_step_ms("fp16", steps=30, warmup=10), "bf16": train_step_ms("bf16", steps=30, warmup=10)}
+
+
 def cfg1_figures():
     """BASELINE.json configs[0]: one 4 s clip, 16 kHz, 60 harmonics, batch 1 -- the reference's CPU-runnable case.  Here: the GPU
     latency of one OscillatorBank.forward + FilteredNoise call (median of 50, synchronised); the CPU figure: cfg1_cpu."""
@@ -616,8 +624,7 @@ def main():
                                "cfg2": time_config(syn.CFG2, 1002, 10, 2), "cfg3": time_config(syn.CFG3, 1003, 10, 2),
                                "musical": time_config(syn.CFG4_PER_GPU, 1004, 10, 2, f0_kind="musical"),
                                "live_callback": live_callback_ms(),
-                               "train_step": {"note": "BASELINE.json configs[4] per-GPU shape on this one GPU (no all-reduce)",
-                                              "fp16_gradscaler": train_step_ms("fp16"), "bf16": train_step_ms("bf16")}}
+                               "train_step": train_step_figures()}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(shape)
             if "configs" in line:
