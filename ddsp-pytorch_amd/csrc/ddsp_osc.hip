@@ -648,8 +648,9 @@ extern "C" int ddsp_osc_set_tiling(int harmonics_per_lane)
 extern "C" int ddsp_osc_set_path(int path)
 {
     if (path != 0 && !ddsp_hooks_on()) return DDSP_EPERM;
-    if (path < 0 || path > 1) return DDSP_ERANGE;
-    g_path.store(path, std::memory_order_relaxed);
+    if (path < 0 || path > 2) return DDSP_ERANGE;
+    g_path.store(path == 1 ? 1 : 0, std::memory_order_relaxed);
+    g_chunk_any_batch.store(path == 2 ? 1 : 0, std::memory_order_relaxed);
     return 0;
 }
 

@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
 #include <stdlib.h>
 
@@ -722,6 +723,8 @@ hipError_t synth_residency(Residency *out)
 
 namespace ddsp_osc {
 
+std::atomic<int> g_chunk_any_batch{0};   // ddsp_osc_set_path(2): chunked form whatever the batch's fill of the row blocks (tests)
+
 // Chunk length.  A compute unit takes whole workgroups (4 wavefronts, one per SIMD), at most `wg_per_cu` at a time, and a
 // SIMD's throughput is about the same with 2 or 3 resident wavefronts (half of it with 1): the run time is the number of
 // workgroups the fullest unit gets times one chunk's walk.  Preferred: every (row block, chunk) task resident at once and the
@@ -760,8 +763,13 @@ void pick_chunks(int T, int R, int RB, int cus, int wg_per_cu, int *Lc_out, int 
 
 bool chunked_eligible(const OscParams &p)
 {
-    return p.pow2 && p.R >= 64 && p.R <= 8192 && p.logG >= 2 && p.logG <= 4 && !p.live_in && !p.live_out && !p.dbg_phi &&
-           (long)p.B * p.T * p.H < (1L << 29);   // 32-bit byte offsets into the scratch arrays
+    if (!(p.pow2 && p.R >= 64 && p.R <= 8192 && p.logG >= 2 && p.logG <= 4 && !p.live_in && !p.live_out && !p.dbg_phi &&
+          (long)p.B * p.T * p.H < (1L << 29)))   // 32-bit byte offsets into the scratch arrays
+        return false;
+    // a wavefront takes 64/G ROWS: a batch that fills its last row block badly (3 rows of 8, 9 of 16) idles those lanes for the
+    // whole walk, which the frame kernels (consecutive frames of one row per wavefront) do not -- they are ~9 % slower when full
+    const int gpw = 64 >> p.logG, rb = (p.B + gpw - 1) / gpw;
+    return (long)p.B * 100 >= (long)rb * gpw * 88 || g_chunk_any_batch.load(std::memory_order_relaxed);
 }
 
 // The chunked layout keeps the frame layout's first parts (w | amp | fp64 region: ctot [B,NC,H] fits where loc [B,T,H] sits,

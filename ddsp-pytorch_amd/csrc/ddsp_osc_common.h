@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace ddsp_osc {
 
 
@@ -185,6 +187,7 @@ inline size_t sup_elems(int B, int T, int H) { return (size_t)B * ((size_t)(T + 
 bool setup_params(OscParams &p, void *scratch, int B, int T, int H, int hop, int sample_rate);
 // chunked form (ddsp_osc_chunk.hip)
 bool chunked_eligible(const OscParams &p);
+extern std::atomic<int> g_chunk_any_batch;
 size_t chunk_scratch_bytes(int B, int T, int H);
 size_t frame_scratch_bytes(int B, int T, int H);
 void pick_chunks(int T, int R, int RB, int cus, int wg_per_cu, int *Lc_out, int *NC_out);

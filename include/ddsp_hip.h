@@ -124,7 +124,8 @@ int ddsp_noise_backward_counter(const float *grad_y, float *grad_H, int B, int T
  */
 int ddsp_osc_set_tiling(int harmonics_per_lane);
 /* Test / tuning hook: 1 = frame kernels for every shape (the round 1-3 decomposition, one lane group per frame), 0 = automatic
- * (chunked form where it applies).  Same results within rounding. */
+ * (chunked form where it applies and the batch fills the row blocks to >= 88 %), 2 = chunked form for every eligible shape
+ * whatever the batch (tests of small batches).  Same results within rounding. */
 int ddsp_osc_set_path(int path);
 /* What ddsp_osc_forward would launch for this shape on the current device (HOST array of >= 8 ints): out[0] harmonics per
  * lane, [1] lanes per row group, [2] 1 = chunked form, then its [3] chunk length in samples, [4] chunks per row,

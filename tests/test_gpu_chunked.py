@@ -48,6 +48,7 @@ def force_chunked(L, K, B, T, H, hop, sr):
     """Pins the harmonics per lane (small problems would otherwise pick 32+ lanes per row, which the chunked form leaves
     to the frame kernels) and returns the launch plan, which must say `chunked`."""
     ddsp._lib.check(L.ddsp_osc_set_tiling(K), "ddsp_osc_set_tiling")
+    ddsp._lib.check(L.ddsp_osc_set_path(2), "ddsp_osc_set_path")      # ... and batches that fill their last row block badly
     plan = ddsp._lib.osc_plan(B, T, H, hop, sr)
     assert plan["chunked"] == 1 and plan["harmonics_per_lane"] == K, plan
     return plan
@@ -161,9 +162,11 @@ def test_plan_reports_the_launch(lib):
     # every (row block, chunk) task resident at once on this device
     tasks = plan["row_blocks"] * plan["chunks_per_row"]
     assert tasks <= plan["compute_units"] * plan["workgroups_per_unit"] * 4
-    # shapes the chunked form leaves to the frame kernels: odd hop, short hop, live state
+    # shapes the chunked form leaves to the frame kernels: odd hop, short hop, a batch that fills 9 of 16 row slots
     assert ddsp._lib.osc_plan(512, 500, 100, 100, 16000)["chunked"] == 0
     assert ddsp._lib.osc_plan(512, 500, 100, 32, 16000)["chunked"] == 0
+    assert ddsp._lib.osc_plan(9, 4000, 100, 128, 16000)["chunked"] == 0
+    assert ddsp._lib.osc_plan(15, 4000, 100, 128, 16000)["chunked"] == 1
 
 
 def test_backward_refuses_a_chunked_scratch(lib):

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Only the oscillator at a BASELINE shape, N times (for rocprofv3 passes): osc_only.py <frame|chunk> [steps] [cfg4|cfg2|cfg3] [all_live|musical]"""
+"""Only the oscillator at a BASELINE shape, N times (for rocprofv3 passes):
+osc_only.py <frame|chunk|chunk_any> [steps] [cfg1|cfg2|cfg3|cfg4|b<rows>] [all_live|musical]"""
 import json
 import os
 import sys
@@ -15,9 +16,13 @@ from ddsp_pytorch_amd import synthetic as syn  # noqa: E402
 
 path = sys.argv[1] if len(sys.argv) > 1 else "chunk"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-shape = {"cfg4": syn.CFG4_PER_GPU, "cfg2": syn.CFG2, "cfg3": syn.CFG3}[sys.argv[3] if len(sys.argv) > 3 else "cfg4"]
+_name = sys.argv[3] if len(sys.argv) > 3 else "cfg4"
+if _name.startswith("b"):      # b<rows>: the headline shape with that many rows and 8x longer clips
+    shape = syn.SynthShape(_name, int(_name[1:]), 16000, 128, 4000, 100, 65)
+else:
+    shape = {"cfg1": syn.CFG1, "cfg4": syn.CFG4_PER_GPU, "cfg2": syn.CFG2, "cfg3": syn.CFG3}[_name]
 kind = sys.argv[4] if len(sys.argv) > 4 else "all_live"
-assert ddsp._lib.lib().ddsp_osc_set_path(1 if path == "frame" else 0) == 0
+assert ddsp._lib.lib().ddsp_osc_set_path({"frame": 1, "chunk": 0, "chunk_any": 2}[path]) == 0
 ctl = syn.make_controls(shape, 1004, kind)
 x = {k: torch.from_numpy(v).cuda() for k, v in ctl.items() if k != "H"}
 plan = ddsp._lib.osc_plan(shape.batch, shape.frames, shape.n_harmonics, shape.hop, shape.sample_rate)
