@@ -97,7 +97,8 @@ template <int K>
 struct ChunkState {
     double acc[K];
     float x0[K], x1[K];  // increments of the segment's bracketing rows
-    float a0[K], da[K];  // amplitude of the older row and (newer - older)   (synth only)
+    float a1[K], da[K];  // amplitude of the NEWER row and (newer - older): A(n) = a1 - w0 * da, so that crossing into the next
+                         // segment needs the new row only (the older amplitude is the a1 already held)   (synth only)
 };
 
 struct Task {
@@ -241,7 +242,7 @@ __device__ __forceinline__ void walk_synth(const OscParams &p, ChunkState<K> &st
 #pragma unroll
         for (int e = 0; e < NS; ++e)
 #pragma unroll
-            for (int m = 0; m < KL; ++m) q[e][m] = __fmaf_rn(w1[e], st.da[m], st.a0[m]);
+            for (int m = 0; m < KL; ++m) q[e][m] = __fmaf_rn(-w0[e], st.da[m], st.a1[m]);
         DDSP_STAGE_END();
         float s0[NS], s1[NS];
 #pragma unroll
@@ -322,7 +323,7 @@ __device__ __forceinline__ void walk_synth_exact(const OscParams &p, ChunkState<
             st.acc[m] += (double)inc;
             const float r = remainder_two_pi((float)st.acc[m]);   // :42, exact
             const float sn = __builtin_amdgcn_sinf(r * kRevPerRad);
-            sum = __fmaf_rn(__fmaf_rn(w1, st.da[m], st.a0[m]), sn, sum);
+            sum = __fmaf_rn(__fmaf_rn(-w0, st.da[m], st.a1[m]), sn, sum);
         }
         sum = group_sum(sum, p.logG);
         if (j == 0 && active) yrow[i_abs + (n - n_beg)] = __fmaf_rn(w0, L0, w1 * L1) * sum;
@@ -622,7 +623,7 @@ __global__ void __launch_bounds__(256, (!EXACT && K <= 13) ? 3 : 1) osc_chunk_sy
                 const unsigned g = (unsigned)(m * G);
                 t0[m] = first ? ldf(p.w, o0 + g) : 0.0f;
                 t1[m] = ldf(p.w, o1 + g);
-                u0[m] = ldf(p.amp, o0 + g);
+                u0[m] = first ? ldf(p.amp, o0 + g) : 0.0f;
                 u1[m] = ldf(p.amp, o1 + g);
             }
 #pragma unroll
@@ -630,10 +631,11 @@ __global__ void __launch_bounds__(256, (!EXACT && K <= 13) ? 3 : 1) osc_chunk_sy
                 const bool ok = k.j + m * G < p.H;
                 if (first) st.x0[m] = ok ? t0[m] : 0.0f;
                 st.x1[m] = ok ? t1[m] : 0.0f;
-                st.a0[m] = ok ? u0[m] : 0.0f;
-                st.da[m] = ok ? u1[m] - u0[m] : 0.0f;
+                const float older = first ? (ok ? u0[m] : 0.0f) : st.a1[m];   // (after the first segment: the row already held)
+                st.a1[m] = ok ? u1[m] : 0.0f;
+                st.da[m] = st.a1[m] - older;
             }
-            L0 = p.a[rowbase + ra];
+            if (first) L0 = p.a[rowbase + ra]; else L0 = L1;
             L1 = p.a[rowbase + rb2];
         };
         load_rows(r0, r1, true);
