@@ -456,14 +456,18 @@ __global__ void __launch_bounds__(256, (SKIP && K <= 13) ? 3 : 1) osc_synth_kern
         constexpr int KQ = (K + 3) / 4, KH = (K + 1) / 2;
         int mlive = K;
         if (SKIP) {
+            // from f0 (three loads) instead of the 3 x K amplitudes themselves (39 loads and their addresses: the registers this
+            // variant spilled): a harmonic above Nyquist at all three bracketing frames has amplitude exactly zero there (:31-32).
+            // Zero amplitudes BELOW Nyquist are simply walked; NaN f0 compares false -> kept; an all-masked frame (NaN amplitudes,
+            // :33) still reaches the output through slot 0, which every walk includes.
             mlive = 0;
-            const float *ab = p.amp + (long)b * p.T * p.H;
+            const long rowbase = (long)b * p.T;
+            const float fmin3 = fminf(fminf(p.f0[rowbase + ia], p.f0[rowbase + ib]), p.f0[rowbase + ic]);
 #pragma unroll
             for (int m = 0; m < K; ++m) {
                 const int h = j + m * G;
-                bool nz = false;
-                if (h < p.H) nz = (ab[(long)ia * p.H + h] != 0.0f) || (ab[(long)ib * p.H + h] != 0.0f) || (ab[(long)ic * p.H + h] != 0.0f);
-                if (__any(nz)) mlive = m + 1;   // NaN amplitudes (all-masked frame) compare != 0: kept
+                const bool keep = h < p.H && !((float)(h + 1) * fmin3 > p.nyquist);
+                if (__any(keep)) mlive = m + 1;
             }
         }
 #define DDSP_WALK2(KL, NS)                                                                                   \
@@ -471,7 +475,12 @@ __global__ void __launch_bounds__(256, (SKIP && K <= 13) ? 3 : 1) osc_synth_kern
             load_synth_segment<K>(p, st, b, j, ia, t == 0 ? ic : ib, L0, L1);   /* frame 0 clamps to source 0 but keeps neighbour 1 */                                              \
             if (POW2) walk_fast<K, MODE_SYNTH, true, KL, NS, !SKIP>(p, st, b, t, j, active, ia, L0, L1, 0, p.R >> 1);   \
             else      walk_fast<K, MODE_SYNTH, false, KL, 1>(p, st, b, t, j, active, ia, L0, L1, 0, split);  \
-            load_synth_segment<K>(p, st, b, j, ib, ic, L0, L1);                                              \
+            {   /* (opaque copies: otherwise the compiler forms the second segment's row addresses before the first walk and    \
+                   spills the 64-bit pairs across it -- the 10 spilled registers of round 3's SKIP variant) */                 \
+                int ib2 = ib, ic2 = ic;                                                                      \
+                asm volatile("" : "+v"(ib2), "+v"(ic2));                                                     \
+                load_synth_segment<K>(p, st, b, j, ib2, ic2, L0, L1);                                        \
+            }                                                                                                \
             if (POW2) walk_fast<K, MODE_SYNTH, true, KL, NS, !SKIP>(p, st, b, t, j, active, ib, L0, L1, p.R >> 1, p.R); \
             else      walk_fast<K, MODE_SYNTH, false, KL, 1>(p, st, b, t, j, active, ib, L0, L1, split, p.R); \
         } while (0)
