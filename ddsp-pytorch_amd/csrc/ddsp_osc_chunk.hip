@@ -63,7 +63,7 @@ __device__ __forceinline__ void segment_lambda(const OscParams &p, int n, bool c
 // run (measured: tools/microbench/osc_stamps.py), and the last one walks alone at half the SIMD's throughput.  With ONE round of
 // resident wavefronts nothing backfills, so the wavefronts take turns instead: priority level (slot + epoch) mod 3 with `slot`
 // the hardware wave slot on the SIMD (HW_ID[3:0]: 0, 1, 2 when three are resident) and `epoch` = the 100 MHz wall clock in
-// units of about a twelfth of the kernel's expected run time (host: turn_shift), which every wavefront of the SIMD reads alike -- the three levels are always all different, each wavefront
+// units of about a tenth of the kernel's expected run time (host: turn_shift), which every wavefront of the SIMD reads alike -- the three levels are always all different, each wavefront
 // holds each of them a third of the time, and all of them reach the end together.  (Rotating with a wavefront's own progress
 // instead drifts into equal levels, where age decides again: slot 0 still finished 25 % early.)
 __device__ __forceinline__ int wave_slot()
@@ -339,7 +339,7 @@ __device__ __forceinline__ void walk_totals(const OscParams &p, double (&acc)[K]
     segment_lambda(p, n_beg, clamp0, lam, dlam);
     float mal = 1.0f - lam;
     for (int nb = n_beg; nb < n_end; nb += 16) {
-    take_turn(slot, p.nres, p.turn_shift - 2);
+    take_turn(slot, p.nres, p.turn_shift);
     for (int n = nb; n < nb + 16; ++n) {
         const float w1 = lam, w0 = mal;
         lam += dlam;
@@ -804,11 +804,18 @@ hipError_t chunk_geometry(OscParams &p, Residency *res_out)
         }
     }
     p.nres = res.wg_per_cu < 3 ? (res.wg_per_cu < 1 ? 1 : res.wg_per_cu) : 3;
-    {   // turn-taking epoch = about 1/12 of the synth kernel's run: a chunk walk costs ~0.056 us per sample and harmonic slot
+    {   // turn-taking epoch = 1/12 .. 1/6 of the synth kernel's run (a chunk walk costs ~0.056 us per sample and harmonic slot); the
+        // totals kernel, a third as long, takes the same epoch: sweeps in profiles/r04_wave_fairness.txt (shorter epochs leave a
+        // low-priority wavefront more of each epoch before it looks at the clock again; longer ones too few rotations)
         const double ticks = (double)p.Lc * (double)p.K * 5.6;   // 100 MHz ticks
         int sh = 8;
-        while (sh < 16 && (double)(1 << (sh + 1)) <= ticks / 12.0) ++sh;
+        while (sh < 16 && (double)(1 << (sh + 1)) <= ticks / 6.0) ++sh;
         p.turn_shift = sh;
+        if (ddsp_hooks_on()) {   // tuning experiments only
+            const char *e = getenv("DDSP_OSC_TURN_SHIFT");
+            const int v = e ? atoi(e) : 0;
+            if (v >= 6 && v <= 20) p.turn_shift = v;
+        }
     }
     *res_out = res;
     return hipSuccess;

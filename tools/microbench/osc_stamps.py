@@ -55,6 +55,22 @@ cus = collections.Counter((int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i])) for 
 print("waves per CU: histogram:", collections.Counter(cus.values()), "distinct CUs:", len(cus))
 for w in sorted(set(int(v) for v in wslot)):
     print("wave slot", w, "n", int((wslot == w).sum()), "median end", round(float(np.median(end[wslot == w])), 1))
+full = dur > 0.9 * np.median(dur)                      # (drop the shorter last chunks of every row)
+for name, key in (("SIMD id", simd), ("shader array", sh), ("shader engine", se), ("CU id", cu), ("XCC", xcc)):
+    print("median / max end by", name, {int(v): (round(float(np.median(end[full & (key == v)])), 1), round(float(end[full & (key == v)].max()), 1))
+                                        for v in sorted(set(int(q) for q in key))})
+simd_end = collections.defaultdict(float)
+for i in range(n):
+    kk = (int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i]), int(simd[i]))
+    simd_end[kk] = max(simd_end[kk], float(end[i]))
+v = np.array(list(simd_end.values()))
+print("last end per SIMD: min %.1f  5%% %.1f  median %.1f  95%% %.1f  max %.1f" % (v.min(), np.percentile(v, 5), np.median(v), np.percentile(v, 95), v.max()))
+cu_end = collections.defaultdict(list)
+for kk, e in simd_end.items():
+    cu_end[kk[:4]].append(e)
+spread = np.array([max(x) - min(x) for x in cu_end.values()])
+print("spread of the four SIMDs' last ends inside a CU: median %.1f  max %.1f us; between CU means: std %.1f us" % (
+    np.median(spread), spread.max(), float(np.std([np.mean(x) for x in cu_end.values()]))))
 # duration against co-residency
 cnt = np.array([slot[(int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i]), int(simd[i]))] for i in range(n)])
 for c in sorted(set(cnt)):
