@@ -291,6 +291,47 @@ def cfg1_cpu():
             "cpu_kind": "port (oracle/torch_restatement.py: the reference's torch-op sequence)"}
 
 
+def live_traffic(f0_kind):
+    """HBM bytes per launch of the oscillator's synth kernel measured on THIS box, now: two rocprofv3 counter passes (FETCH_SIZE,
+    WRITE_SIZE: they do not fit one pass) of a child process that runs the same oscillator workload three times
+    (tools/microbench/osc_only.py), corrected as MI355X_MICROARCH.md prescribes (KiB units; gfx950's FETCH_SIZE counts half of the
+    bytes of coalesced reads).  -> (bytes, description) or (None, reason); never raises.  Skipped when this process itself runs under
+    a profiler."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None, "bench.py runs under a profiler"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="ddsp_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", DDSP_TEST_HOOKS="1")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(out, counter), "--",
+                                sys.executable, os.path.join(ROOT, "tools", "microbench", "osc_only.py"), "chunk", "3", "cfg4", f0_kind],
+                               env=env, cwd="/tmp", timeout=180, capture_output=True)
+            acc = []
+            for f in glob.glob(os.path.join(out, counter, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    k = row["Kernel_Name"]
+                    if row["Counter_Name"] == counter and ("osc_chunk_synth_kernel" in k or "osc_synth_kernel" in k):
+                        acc.append(float(row["Counter_Value"]))
+            acc = [v for v in acc if v > 0.25 * max(acc)] if acc else acc      # (the repair / twin launches that return at once)
+            if not acc:
+                return None, f"no {counter} rows (rocprofv3 exit {r.returncode})"
+            vals[counter] = sum(acc) / len(acc)
+    except Exception as e:  # noqa: BLE001
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    return 2.0 * vals["FETCH_SIZE"] * 1024.0 + vals["WRITE_SIZE"] * 1024.0, \
+        "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) of tools/microbench/osc_only.py on this box, after the timed region; 2 x FETCH_SIZE + WRITE_SIZE, KiB"
+
+
 def cpu_baseline(shape, seconds_target=12.0):
     """Reference CPU path (torch-op restatement) on a bounded sample: B=8 rows of the same workload."""
     from oracle import torch_restatement as tr
@@ -420,6 +461,8 @@ def main():
     ap.add_argument("--tiling", type=int, default=0, help="force harmonics per lane (tuning)")
     ap.add_argument("--harmonics", type=int, default=0, help="override the number of harmonics (tuning experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure roofline.traffic with two rocprofv3 child passes after the timed region (N = 1); use the committed profile")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary figures (cfg1, cfg2, cfg3, musical f0, live callback, training step) timed after the headline at N = 1")
     ap.add_argument("--mode", default="synth", choices=["synth", "train"],
@@ -552,6 +595,13 @@ def main():
 
         traffic = traffic_of("osc_chunk_synth_kernel") or traffic_of("osc_synth_kernel")
         traffic_src = f"profiles/{pmc_name} (FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None
+        traffic_committed = traffic
+        if world == 1 and not args.no_live_pmc and not (args.batch or args.tiling or args.harmonics):
+            live, how = live_traffic(args.f0)
+            if live:
+                traffic, traffic_src = live, how
+            else:
+                traffic_src = (traffic_src or "none") + f" [live measurement skipped: {how}]"
         # the kernel SURVEY §8(d) says can approach the HBM roof: 4 (y) + 4 F / hop (H) bytes per sample (the draw is made
         # in the kernel; the accumulate's read of y is the oscillator's output coming back, not counted as algorithmic)
         noise_ms = kern_ms.get("noise_frame", float("nan"))
@@ -581,6 +631,7 @@ def main():
             "kernel_Mcycles": {k: v * 1e-3 * clock * 1e3 for k, v in kern_ms.items()} if clock else None,
             "roofline": {"bound": "hbm", "kernel": "osc_frame_synth", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_committed_profile": traffic_committed,
                          "algorithmic_bytes_per_launch": launch_samples * bytes_per_sample,
                          "algorithmic_bytes_per_sample": bytes_per_sample, "avg_launch_ms": synth_ms,
                          "note": "kernel is VALU-bound (SURVEY §8d): see valu",
