@@ -5,8 +5,9 @@
 //   * The row's samples are cut into CHUNKS of Lc samples (a multiple of 32, >= hop), chosen on the host so that
 //     every (row block, chunk) task is resident at once: ONE round of wavefronts, no tail of partly filled rounds.
 //   * A wavefront = one chunk index of 64/G consecutive batch rows (G lanes per row, K harmonics per lane, as in the
-//     frame kernels); every lane group is at the same sample offset, so loop bounds and interpolation weights are
-//     wave-uniform and live in scalar registers.
+//     frame kernels); every lane group is at the same sample offset, so loop bounds are wave-uniform.  The wavefronts of a
+//     SIMD take turns by rotating their priority on the wall clock (take_turn): without that the oldest one runs ahead and
+//     the last one finishes alone.
 //   * Inside a chunk the lanes walk SEGMENTS: segment s = samples [s*hop - hop/2, s*hop + hop/2) is the stretch over
 //     which F.interpolate (:52-55) uses the ONE bracketing pair (s-1, s) with weight (2n+1)/(2 hop), n = 0..hop-1
 //     (clamped at both clip ends).  Crossing into the next segment costs one row of increments and amplitudes;
@@ -16,8 +17,8 @@
 //     sample in the flush, not once per lane and sample.
 //
 //   * Silent harmonics (above Nyquist, :31-32) are skipped per chunk: pass 1 records, per (row, chunk), the highest
-//     harmonic slot that is audible anywhere in the chunk; a wavefront walks 1/8, 1/4, 1/2, 3/4 or all of the K slots, and pass 2 orders the rows
-//     of every chunk index so that rows which stop at the same slot share a wavefront.
+//     harmonic slot that is audible anywhere in the chunk; a wavefront walks 1/8, 1/4, 1/2, 3/4 or all of the K slots,
+//     and pass 2 orders the rows of every chunk index so that rows which stop at the same slot share a wavefront.
 //
 // Launches: osc_chunk_totals_kernel (rows w / amp, chunk totals, highest audible slot per row and chunk),
 // osc_chunk_scan_kernel (exclusive scan of the chunk totals along the row, flag reset), osc_chunk_synth_kernel
@@ -63,9 +64,10 @@ __device__ __forceinline__ void segment_lambda(const OscParams &p, int n, bool c
 // run (measured: tools/microbench/osc_stamps.py), and the last one walks alone at half the SIMD's throughput.  With ONE round of
 // resident wavefronts nothing backfills, so the wavefronts take turns instead: priority level (slot + epoch) mod 3 with `slot`
 // the hardware wave slot on the SIMD (HW_ID[3:0]: 0, 1, 2 when three are resident) and `epoch` = the 100 MHz wall clock in
-// units of about a tenth of the kernel's expected run time (host: turn_shift), which every wavefront of the SIMD reads alike -- the three levels are always all different, each wavefront
-// holds each of them a third of the time, and all of them reach the end together.  (Rotating with a wavefront's own progress
-// instead drifts into equal levels, where age decides again: slot 0 still finished 25 % early.)
+// units of about a tenth of the kernel's expected run time (host: turn_shift), which every wavefront of the SIMD reads alike --
+// the three levels are always all different, each wavefront holds each of them a third of the time, and all of them reach the
+// end together.  (Rotating with a wavefront's own progress instead drifts into equal levels, where age decides again: slot 0
+// still finished 25 % early.)
 __device__ __forceinline__ int wave_slot()
 {
     return __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));   // HW_REG_HW_ID, bits 3:0 = wave slot on the SIMD
