@@ -356,6 +356,13 @@ __global__ void __launch_bounds__(64, 2) noise_wave_kernel(NoiseParams p, long n
     draw(g * FG);
     DDSP_STAMP(0);
     for (;;) {
+        {   // The two wavefronts of a SIMD take turns at the higher priority, 41 us each (ddsp_osc_chunk.hip: take_turn; the
+            // arbiter otherwise favours the older one for the whole launch and the younger one finishes alone): 0.1034 ->
+            // 0.0995 ms at the bench shape, same box, three interleaved rounds (epochs of 5 / 10 / 20 us: no gain).
+            const unsigned slot = (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));
+            const unsigned epoch = (unsigned)(__builtin_amdgcn_s_memrealtime() >> 12);
+            if ((slot + epoch) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
         const long frame0 = g * FG;
         const long gn = g + gridDim.x;
         const Pass r0 = conv_pass(0);
