@@ -641,6 +641,16 @@ __global__ void __launch_bounds__(256, (!EXACT && K <= 13) ? 3 : 1) osc_chunk_sy
             L1 = p.a[rowbase + rb2];
         };
         load_rows(r0, r1, true);
+#ifdef DDSP_CHUNK_STAMPS
+        long stamp_walk = 0;
+        if (DDSP_CHUNK_STAMPS == 2) {   // (forces the first rows to have arrived: the prologue's length)
+            float chk = 0.0f;
+#pragma unroll
+            for (int m = 0; m < K; ++m) chk += st.x1[m] + st.da[m];
+            if (__any(chk == 123456.0f)) bad = true;
+            stamp_walk = wall_clock64();
+        }
+#endif
         while (true) {
             const int n_end = min(p.R, k.n + (k.i_end - k.i));
             const bool clamp0 = k.s == 0;
@@ -689,7 +699,7 @@ __global__ void __launch_bounds__(256, (!EXACT && K <= 13) ? 3 : 1) osc_chunk_sy
                 g_stamps[wt * 4 + 0] = stamp0;
                 g_stamps[wt * 4 + 1] = wall_clock64();
                 g_stamps[wt * 4 + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
-                g_stamps[wt * 4 + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+                g_stamps[wt * 4 + 3] = DDSP_CHUNK_STAMPS == 2 ? stamp_walk : (long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID, or the first walk's start
             }
 #endif
         }

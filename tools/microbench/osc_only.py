@@ -17,7 +17,12 @@ from ddsp_pytorch_amd import synthetic as syn  # noqa: E402
 path = sys.argv[1] if len(sys.argv) > 1 else "chunk"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 _name = sys.argv[3] if len(sys.argv) > 3 else "cfg4"
-if _name.startswith("b"):      # b<rows>: the headline shape with that many rows and 8x longer clips
+if _name.startswith("s") and "x" in _name:   # s<rows>x<frames>x<hop>x<harmonics>: any shape (48 kHz so that every harmonic is audible)
+    _b, _t, _h, _k = (int(v) for v in _name[1:].split("x"))
+    shape = syn.SynthShape(_name, _b, 48000, _h, _t, _k, 65)
+elif _name.startswith("hop"):    # hop<n>: the headline shape (512 rows, 100 harmonics, 64 000 samples) at another hop
+    shape = syn.SynthShape(_name, 512, 16000, int(_name[3:]), 64000 // int(_name[3:]), 100, 65)
+elif _name.startswith("b"):    # b<rows>: the headline shape with that many rows and 8x longer clips
     shape = syn.SynthShape(_name, int(_name[1:]), 16000, 128, 4000, 100, 65)
 else:
     shape = {"cfg1": syn.CFG1, "cfg4": syn.CFG4_PER_GPU, "cfg2": syn.CFG2, "cfg3": syn.CFG3}[_name]

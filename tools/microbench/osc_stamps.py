@@ -15,7 +15,12 @@ sys.path.insert(0, ROOT)
 import ddsp_pytorch_amd as ddsp  # noqa: E402
 from ddsp_pytorch_amd import synthetic as syn  # noqa: E402
 
-shape = {"cfg4": syn.CFG4_PER_GPU, "cfg2": syn.CFG2, "cfg3": syn.CFG3}[sys.argv[1] if len(sys.argv) > 1 else "cfg4"]
+_name = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
+if _name.startswith("s") and "x" in _name:   # s<rows>x<frames>x<hop>x<harmonics> at 48 kHz
+    _b, _t, _h, _k = (int(v) for v in _name[1:].split("x"))
+    shape = syn.SynthShape(_name, _b, 48000, _h, _t, _k, 65)
+else:
+    shape = {"cfg4": syn.CFG4_PER_GPU, "cfg2": syn.CFG2, "cfg3": syn.CFG3}[_name]
 ctl = syn.make_controls(shape, 1004, "all_live")
 x = {k: torch.from_numpy(v).cuda() for k, v in ctl.items() if k != "H"}
 plan = ddsp._lib.osc_plan(shape.batch, shape.frames, shape.n_harmonics, shape.hop, shape.sample_rate)
@@ -76,3 +81,13 @@ cnt = np.array([slot[(int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i]), int(simd[
 for c in sorted(set(cnt)):
     print("waves on a SIMD with", c, "tasks: n", int((cnt == c).sum()), "median dur", round(float(np.median(dur[cnt == c])), 1),
           "median start", round(float(np.median(start[cnt == c])), 1))
+# finishing order inside a SIMD (three co-resident tasks)
+order = collections.defaultdict(list)
+for i in range(n):
+    if full[i]:
+        order[(int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i]), int(simd[i]))].append((float(end[i]), float(start[i])))
+trip = np.array([[e for e, _ in sorted(v)] for v in order.values() if len(v) == 3])
+if len(trip):
+    print("SIMDs with three full tasks: %d; median end of the first / second / last to finish: %.1f / %.1f / %.1f us; mean %.1f / %.1f / %.1f" % (
+        len(trip), *np.median(trip, axis=0), *trip.mean(axis=0)))
+    print("work rate of a SIMD, samples per us: 3*Lc/last end = %.3f (median)" % float(np.median(3 * plan["chunk_samples"] / trip[:, 2])))

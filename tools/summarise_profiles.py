@@ -26,6 +26,25 @@ def short(name):
     return None
 
 
+# the launches of bench.py's timed region inside the traced run (bench.py: clock_settle.timed_launches): the run also holds the
+# from-idle pass, the settle steps and the clock probe's launches, so the all-launch average is not the timed region's
+timed = {}
+try:
+    t = json.loads(open(os.path.join(src, "bench_under_rocprof.json")).read().strip().splitlines()[-1])["clock_settle"]["timed_launches"]
+    per = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_trace.csv")):
+        for r in csv.DictReader(open(f)):
+            s = short(r["Kernel_Name"])
+            if s:
+                per[s].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    for s, v in per.items():
+        v.sort()
+        sel = [d for _, d in v[t["first"]:t["first"] + t["count"]]]
+        if len(sel) == t["count"]:
+            timed[s] = sum(sel) / len(sel)
+except Exception as e:  # noqa: BLE001
+    print("no timed-region split:", e)
+
 stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
 rows = []
 if stats:
@@ -33,7 +52,8 @@ if stats:
         s = short(r["Name"])
         if s:
             rows.append({"kernel": s, "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": int(r["MinNs"]),
-                         "max_ns": int(r["MaxNs"]), "pct": float(r["Percentage"])})
+                         "max_ns": int(r["MaxNs"]), "pct": float(r["Percentage"]),
+                         "timed_region_avg_ns": round(timed[s], 1) if s in timed else ""})
     with open(os.path.join(dst, f"{rnd}_kernel_stats.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         w.writeheader()
