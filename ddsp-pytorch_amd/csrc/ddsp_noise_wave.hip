@@ -2,7 +2,7 @@
 // Same arithmetic contract as ddsp_noise.hip (model/ddsp/filtered_noise.py:7-53); different organisation (noise section):
 //
 //   * ONE WAVEFRONT owns a group of 16 frames at a time and shares nothing with other wavefronts: no workgroup barrier anywhere
-//     (64-thread workgroups, 17.4 KB of LDS each, SIX per CU -- launch_noise_wave says why not eight; LDS operations of one wavefront execute in order,
+//     (64-thread workgroups, 17.4 KB of LDS each, FIVE per CU -- launch_noise_wave says why not eight; LDS operations of one wavefront execute in order,
 //     which is all the hand-offs between the stages need).  Persistent: a wavefront walks groups g, g + grid, ...
 //   * software pipeline over the groups, written so that every global access sits in straight-line code (the compiler's
 //     `s_waitcnt vmcnt` are then exact counts, not drains): the NEXT group's filter magnitudes (16 x 65 contiguous floats) are
@@ -414,15 +414,19 @@ long launch_noise_wave(const NoiseParams &p, hipStream_t s, hipError_t *err)
     }
     cus = cached[dev & 63];
     constexpr size_t lds = sizeof(float) * kLdsFloats;
-    // SIX wavefronts per CU (17.4 KB of LDS each), not the eight that fit two per SIMD: at eight the kernel's FMA + LDS + HBM activity
-    // trips the chip's power management, which drops the shader clock from 2.41 to ~2.14 GHz and takes ~25 ms of load to give it back
-    // -- so the oscillator's kernels of the NEXT step pay 0.18 ms for the 0.02 ms saved here.  Seven stay under the trip point on the
-    // boxes measured; six leave a margin (profiles/r04_clock_ramp.txt; DDSP_NOISE_WAVES_PER_CU: tools/build_variant.sh sweeps)
+    // FIVE wavefronts per CU (17.4 KB of LDS each), not the eight that fit two per SIMD: at eight, this kernel's FMA + LDS + HBM
+    // activity makes the chip's power management drop the shader clock (2.41 -> ~2.14 GHz; it takes ~25 ms of load to come back), so
+    // the oscillator's kernels of the NEXT step pay 0.15 ms for the 0.02 ms saved here.  Where the clock starts to give differs
+    // between boxes (below 8 on one, below 6 on another); five keeps it within 1 % of the oscillator-only clock on both and costs
+    // this kernel 0.02-0.03 ms (profiles/r04_clock_ramp.txt; tools/microbench/noise_residency_sweep.sh)
 #ifndef DDSP_NOISE_WAVES_PER_CU
-#define DDSP_NOISE_WAVES_PER_CU 6
+#define DDSP_NOISE_WAVES_PER_CU 5
 #endif
     // (a launch of at most one group per wavefront at eight per CU -- cfg2, the training step: ~20 us -- is over before the trip)
-    const long resident = ngroups <= (long)cus * 8 ? (long)cus * 8 : (long)cus * DDSP_NOISE_WAVES_PER_CU;
+    long resident = ngroups <= (long)cus * 8 ? (long)cus * 8 : (long)cus * DDSP_NOISE_WAVES_PER_CU;
+    // tuning experiments (DDSP_TEST_HOOKS=1 processes only; read once): wavefronts per CU
+    static const long env_waves = [] { const char *ev = getenv("DDSP_NOISE_WAVES"); return (ev && ddsp_hooks_on()) ? atol(ev) : 0L; }();
+    if (env_waves > 0 && env_waves <= 8) resident = (long)cus * env_waves;
     const long grid = ngroups < resident ? ngroups : resident;
     const int slot = ddsp_prof::begin(ddsp_prof::NOISE, s);
     if (p.accumulate) hipLaunchKernelGGL(noise_wave_kernel<true>, dim3((unsigned)grid), dim3(64), lds, s, p, ngroups);

@@ -55,6 +55,9 @@ def series(name, shape, steps, with_noise):
 
 
 EVERY = int(os.environ.get("NOISE_EVERY", "1"))
+if len(sys.argv) > 1 and sys.argv[1] == "osc":
+    series("headline", syn.CFG4_PER_GPU, 120, False)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "write_only":
     series("headline", syn.CFG4_PER_GPU, 120, "write_only")
     sys.exit(0)
