@@ -6,7 +6,7 @@
 bool ddsp_hooks_on();
 
 namespace ddsp_prof {
-enum KernelId { PREP = 0, TOTALS = 1, SCAN = 2, SYNTH = 3, NOISE = 4 };
+enum KernelId { PREP = 0, TOTALS = 1, SCAN = 2, SYNTH = 3, NOISE = 4, NOISE_IR = 5 };
 // Record an event pair around one launch on `s` when profiling is enabled (no-ops otherwise).
 int begin(int kernel_id, hipStream_t s);
 void end(int slot, hipStream_t s);

@@ -552,25 +552,43 @@ int pick_lpf_log(int F, int R, int mode)
 
 namespace {
 int noise_forward_impl(const float *Hmag, const float *uniform, float *y, int B, int T, int F, int hop, uint64_t seed,
-                       uint64_t offset, const uint64_t *offset_dev, int accumulate, void *stream);
+                       uint64_t offset, const uint64_t *offset_dev, int accumulate, void *workspace, size_t workspace_bytes,
+                       void *stream);
+constexpr long kIrProductMinFrames = 256;   // fewer frames (the real-time callback's 4): the cosine operand alone is more work
 }
 
 extern "C" int ddsp_noise_forward(const float *Hmag, const float *uniform, float *y, int B, int T, int F, int hop,
                                   uint64_t seed, uint64_t offset, int accumulate, void *stream)
 {
-    return noise_forward_impl(Hmag, uniform, y, B, T, F, hop, seed, offset, nullptr, accumulate, stream);
+    return noise_forward_impl(Hmag, uniform, y, B, T, F, hop, seed, offset, nullptr, accumulate, nullptr, 0, stream);
 }
 
 extern "C" int ddsp_noise_forward_counter(const float *Hmag, float *y, int B, int T, int F, int hop, uint64_t seed,
                                           const uint64_t *counter_dev, int accumulate, void *stream)
 {
     if (!counter_dev) return DDSP_EINVAL;
-    return noise_forward_impl(Hmag, nullptr, y, B, T, F, hop, seed, 0, counter_dev, accumulate, stream);
+    return noise_forward_impl(Hmag, nullptr, y, B, T, F, hop, seed, 0, counter_dev, accumulate, nullptr, 0, stream);
+}
+
+extern "C" size_t ddsp_noise_workspace_bytes(int B, int T, int F, int hop)
+{
+    if (B <= 0 || T <= 0 || F < 2 || hop <= 0) return 0;
+    const long frames = (long)B * T;
+    return (ir_product_shape(F, hop) && frames >= kIrProductMinFrames) ? ir_workspace_bytes(frames, F) : 0;
+}
+
+extern "C" int ddsp_noise_forward_ws(const float *Hmag, const float *uniform, float *y, int B, int T, int F, int hop, uint64_t seed,
+                                     uint64_t offset, const uint64_t *counter_dev, int accumulate, void *workspace,
+                                     size_t workspace_bytes, void *stream)
+{
+    if (uniform && counter_dev) return DDSP_EINVAL;
+    return noise_forward_impl(Hmag, uniform, y, B, T, F, hop, seed, offset, counter_dev, accumulate, workspace, workspace_bytes, stream);
 }
 
 namespace {
 int noise_forward_impl(const float *Hmag, const float *uniform, float *y, int B, int T, int F, int hop, uint64_t seed,
-                       uint64_t offset, const uint64_t *offset_dev, int accumulate, void *stream)
+                       uint64_t offset, const uint64_t *offset_dev, int accumulate, void *workspace, size_t workspace_bytes,
+                       void *stream)
 {
     if (B == 0) return 0;
     if (!Hmag || !y || B < 0 || T <= 0 || F < 2 || hop <= 0) return DDSP_EINVAL;
@@ -578,9 +596,19 @@ int noise_forward_impl(const float *Hmag, const float *uniform, float *y, int B,
     p.Hm = Hmag; p.u = uniform; p.y = y;
     p.B = B; p.T = T; p.F = F; p.R = hop; p.S = 2 * (F - 1);
     p.seed = seed; p.offset = offset; p.offset_dev = offset_dev; p.accumulate = accumulate; p.lpf_log = 0;
+    p.zrows = nullptr; p.zs = 0;
     if ((long)B * T >= (1L << 31)) return DDSP_ERANGE;
     hipStream_t s = (hipStream_t)stream;
     const int mode = g_force_generic.load(std::memory_order_relaxed);
+    // 195 bands at hop 512 (the reference's default shape) with a workspace: the impulse responses of the whole batch as one
+    // matrix product (ddsp_noise_ir.hip), which the FFT form below then reads instead of summing cosines; mode bit 4 (tests, A/B) keeps the sums
+    if (workspace && !(mode & (3 | 16)) && ir_product_shape(F, hop) && (long)B * T >= kIrProductMinFrames &&
+        workspace_bytes >= ir_workspace_bytes((long)B * T, F) && ((uintptr_t)workspace % 16) == 0) {
+        hipError_t ie = hipSuccess;
+        p.zrows = launch_noise_ir(Hmag, (long)B * T, F, workspace, s, &ie);
+        if (!p.zrows) return (int)ie;
+        p.zs = ir_row_stride(F);
+    }
     // hop 512: the in-LDS FFT form (ddsp_noise_fft.hip); mode bit 1 (tests, A/B) keeps the direct forms, bit 2 takes the
     // FFT form for hop 256 as well (correct there too, just not faster)
     if (!(mode & 3)) {

@@ -14,6 +14,8 @@ struct NoiseParams {
     const uint64_t *offset_dev;  // nullable: the draw starts at offset + *offset_dev (a device counter: hipGraph replays)
     int accumulate;
     int lpf_log; // batched kernel: log2(lanes per frame) -> 64 >> lpf_log frames per workgroup
+    const float *zrows;          // nullable (FFT form only): impulse responses already built by ddsp_noise_ir.hip, [B*T][zs]:
+    int zs;                      //   z[n] * S at columns [0, S/2], max |H| of the frame at column zs - 4
 };
 
 // Philox4x32-10 (Salmon et al. 2011), counter = (c0,c1,0,0), key = seed.
@@ -49,6 +51,13 @@ bool launch_noise_fft(const NoiseParams &p, hipStream_t s, bool force_fft, hipEr
 // nothing) for other shapes.  *err receives the launch status.
 bool launch_noise_fft_backward(const float *grad_y, const float *uniform, float *grad_H, int B, int T, int F, int hop, uint64_t seed,
                                uint64_t offset, const uint64_t *offset_dev, hipStream_t s, hipError_t *err);
+
+// Impulse responses as one split-bf16 matrix product for the whole batch (ddsp_noise_ir.hip): the shapes it is built for, the
+// workspace it needs (| cosine operand | z rows |), and the launch -> the z rows inside the workspace (nullptr: launch error in *err).
+bool ir_product_shape(int F, int hop);
+int ir_row_stride(int F);
+size_t ir_workspace_bytes(long frames, int F);
+const float *launch_noise_ir(const float *Hmag, long frames, int F, void *workspace, hipStream_t s, hipError_t *err);
 
 // Launches the wavefront-private hop-128 / 65-band form (ddsp_noise_wave.hip) on the leading whole groups of 16 frames when the
 // shape is the one it is built for.  Returns the number of frames it took (0: not its shape, nothing launched; the caller runs

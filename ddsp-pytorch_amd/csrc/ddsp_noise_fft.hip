@@ -126,11 +126,31 @@ __global__ void __launch_bounds__(64, 2) noise_fft_kernel(NoiseParams p, long np
     };
     typedef float v4 __attribute__((ext_vector_type(4)));
     struct Lines { v4 v[2][R / 256]; };
+    // impulse responses built beforehand (ddsp_noise_ir.hip; S < R only): z[n] S of a pair, n = lane + 64 e <= S/2, and the frames' max |H|
+    constexpr int ZE = IRFFT ? 1 : R / 128 + 1;
+    struct ZRows { float a[ZE], b[ZE], ma, mb; };
+    auto load_zrows = [&](long pr) {
+        const long fa = 2 * pr, fb = (2 * pr + 1 < nframes) ? 2 * pr + 1 : 2 * pr;
+        const float *za = p.zrows + fa * p.zs, *zb = p.zrows + fb * p.zs;
+        ZRows z;
+#pragma unroll
+        for (int e = 0; e < ZE; ++e) {
+            const int n = min(lane + 64 * e, half);
+            z.a[e] = za[n];
+            z.b[e] = zb[n];
+        }
+        z.ma = za[p.zs - 4];
+        z.mb = zb[p.zs - 4];
+        return z;
+    };
+    const bool have_z = !IRFFT && p.zrows != nullptr;
 
     long pair = blockIdx.x;
     if (pair >= npairs) return;
     Mags hcur;
     if (IRFFT) hcur = load_mags(pair);
+    ZRows zcur;
+    if (have_z) zcur = load_zrows(pair);
     for (;;) {
         FrameSrc fr[2];
         fr[0].frame = 2 * pair;     fr[0].valid = true;
@@ -146,6 +166,8 @@ __global__ void __launch_bounds__(64, 2) noise_fft_kernel(NoiseParams p, long np
         }
         Mags hnext;
         if (IRFFT) hnext = load_mags(next < npairs ? next : pair);            // (the last pair re-reads its own: no branch around the loads)
+        ZRows znext;
+        if (have_z) znext = load_zrows(next < npairs ? next : pair);
 
         // ---- 1. impulse responses -> kk[j] = k_a[j] + i k_b[j] in bufB[0, R) ----------------------------------
         cf h[8];
@@ -184,7 +206,10 @@ __global__ void __launch_bounds__(64, 2) noise_fft_kernel(NoiseParams p, long np
             const float vb = fr[1].valid ? 1.0f : 0.0f;
             for (int j = lane; j < R; j += 64) bufB[j] = make_float2(0.0f, 0.0f);
             DDSP_WAVE_ORDER();
-            {
+            if (have_z) {
+                sca = frame_scale(zcur.ma, 1.0f / (float)S, kOut);
+                scb = frame_scale(zcur.mb, 1.0f / (float)S, kOut);
+            } else {
                 float ma = 0.0f, mb = 0.0f;
                 for (int k = lane; k < F; k += 64) { ma = fmaxf(ma, fabsf(Ha[k])); mb = fmaxf(mb, fabsf(Hb[k])); }
                 sca = frame_scale(ma, 1.0f / (float)S, kOut);
@@ -202,6 +227,14 @@ __global__ void __launch_bounds__(64, 2) noise_fft_kernel(NoiseParams p, long np
                     bufB[jj] = make_float2(za * win, zb * vb * win);
                 }
             };
+            if (have_z) {
+                // z S of both frames was built for the whole batch by one matrix product (ddsp_noise_ir.hip): window and place it
+#pragma unroll
+                for (int e = 0; e < ZE; ++e) {
+                    const int n = lane + 64 * e;
+                    if (n <= half) emit(n, zcur.a[e] * invSa, zcur.b[e] * invSb);
+                }
+            } else {
             const float h0a = Ha[0], hna = Ha[half], h0b = Hb[0], hnb = Hb[half];
             // n = 0 and n = S/2 need no cosines (plain and alternating sums): every lane takes the bins k = lane + 1 + 64 r
             {
@@ -259,6 +292,7 @@ __global__ void __launch_bounds__(64, 2) noise_fft_kernel(NoiseParams p, long np
                     emit(n, __fmaf_rn(2.0f, ea + oa, h0a + sg1 * hna) * invSa, __fmaf_rn(2.0f, eb + ob, h0b + sg1 * hnb) * invSb);
                     if (n2 != n) emit(n2, __fmaf_rn(2.0f, ea - oa, h0a + sg2 * hna) * invSa, __fmaf_rn(2.0f, eb - ob, h0b + sg2 * hnb) * invSb);
                 }
+            }
             }
         }
         DDSP_WAVE_ORDER();
@@ -339,6 +373,13 @@ __global__ void __launch_bounds__(64, 2) noise_fft_kernel(NoiseParams p, long np
             hcur = hnext;
 #pragma unroll
             for (int n1 = 0; n1 < 8; ++n1) { asm volatile("" : "+v"(hcur.a[n1])); asm volatile("" : "+v"(hcur.b[n1])); }
+        }
+        if (have_z) {
+            zcur = znext;
+#pragma unroll
+            for (int e = 0; e < ZE; ++e) { asm volatile("" : "+v"(zcur.a[e])); asm volatile("" : "+v"(zcur.b[e])); }
+            asm volatile("" : "+v"(zcur.ma));
+            asm volatile("" : "+v"(zcur.mb));
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {

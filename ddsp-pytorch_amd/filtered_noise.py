@@ -34,11 +34,18 @@ def noise_forward(Hmag, hop: int, uniform=None, seed: int = 0, offset: int = 0, 
         if tuple(uniform.shape) != (B, T, hop):
             raise ValueError(f"uniform must be [B,T,hop] = {(B, T, hop)}, got {tuple(uniform.shape)}")
         uniform = uniform.detach().to(device=Hmag.device, dtype=torch.float32).contiguous()
+    if counter is not None and (uniform is not None or counter.dtype != torch.int64 or counter.numel() != 1 or not counter.is_cuda):
+        raise ValueError("counter must be a 1-element int64 CUDA tensor and excludes an injected draw")
     with torch.cuda.device(Hmag.device):
         stream = torch.cuda.current_stream().cuda_stream
-        if counter is not None:
-            if uniform is not None or counter.dtype != torch.int64 or counter.numel() != 1 or not counter.is_cuda:
-                raise ValueError("counter must be a 1-element int64 CUDA tensor and excludes an injected draw")
+        ws_bytes = _lib.lib().ddsp_noise_workspace_bytes(B, T, F, hop)
+        if ws_bytes:
+            # (the reference's default shape: impulse responses of the whole batch as one matrix-core product, include/ddsp_hip.h)
+            ws = torch.empty(ws_bytes, device=Hmag.device, dtype=torch.uint8)
+            rc = _lib.lib().ddsp_noise_forward_ws(Hmag.data_ptr(), None if uniform is None else uniform.data_ptr(), out.data_ptr(),
+                                                  B, T, F, hop, seed, offset, None if counter is None else counter.data_ptr(),
+                                                  1 if accumulate else 0, ws.data_ptr(), ws_bytes, stream)
+        elif counter is not None:
             rc = _lib.lib().ddsp_noise_forward_counter(Hmag.data_ptr(), out.data_ptr(), B, T, F, hop, seed, counter.data_ptr(),
                                                        1 if accumulate else 0, stream)
         else:

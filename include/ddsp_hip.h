@@ -94,6 +94,16 @@ int ddsp_noise_forward(const float *Hmag, const float *uniform, float *y,
  * node of the same hipGraph: a replayed graph then draws fresh noise every time).  counter_dev is only read. */
 int ddsp_noise_forward_counter(const float *Hmag, float *y, int B, int T, int F, int hop, uint64_t seed,
                                const uint64_t *counter_dev, int accumulate, void *stream);
+/* The same launch with a caller-provided workspace (device memory, 16-byte aligned, contents undefined before and after).
+ * ddsp_noise_workspace_bytes is 0 for the shapes that have no use for one; for the reference's default shape (195 bands at
+ * hop 512, config/default.py:15,19: 2(F-1) = 388 has no radix-2 transform) at >= 256 frames it holds the cosine operand and the
+ * impulse responses of the whole batch, which are then ONE split-bf16 matrix-core product (csrc/ddsp_noise_ir.hip) instead of
+ * F x S/4 cosine sums per frame pair: 2.2x faster end to end.  A NULL / too small workspace takes the ddsp_noise_forward path
+ * (same results within rounding).  uniform and counter_dev exclude each other (both NULL: the draw starts at `offset`). */
+size_t ddsp_noise_workspace_bytes(int B, int T, int F, int hop);
+int ddsp_noise_forward_ws(const float *Hmag, const float *uniform, float *y, int B, int T, int F, int hop, uint64_t seed,
+                          uint64_t offset, const uint64_t *counter_dev, int accumulate, void *workspace, size_t workspace_bytes,
+                          void *stream);
 
 /*
  * Backward of ddsp_osc_forward w.r.t. c and a (autograd of harmonic_oscillator.py:24-62; f0 carries no gradient,
@@ -139,7 +149,8 @@ int ddsp_osc_clock(const void *scratch, int B, int T, int H, int hop, int sample
 /* Test / tuning hook (process-global, read once per launch): bit 0 forces the generic one-frame-per-workgroup noise kernels
  * (any hop) instead of the batched ones (hop % 8 == 0, tile fits LDS); bit 1 keeps the direct (time-domain) forms where the
  * in-LDS FFT form would run (hop 512 with 2(F-1) <= hop); bit 2 takes the FFT form for hop 256 too (correct, not faster);
- * bit 3 keeps the batched kernel where the wavefront-private form would run (hop 128, 65 bands);
+ * bit 3 keeps the batched kernel where the wavefront-private form would run (hop 128, 65 bands); bit 4 keeps the cosine sums
+ * where ddsp_noise_forward_ws would take the matrix product;
  * (l + 1) << 8 forces 64 >> l frames per workgroup in the batched forward kernel (l = 0..3); 0 restores the defaults.
  * Same results within rounding. */
 int ddsp_noise_set_generic(int on);

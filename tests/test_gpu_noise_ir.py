@@ -1,0 +1,122 @@
+"""The reference's default noise shape (195 bands at hop 512, config/default.py:15,19) through ddsp_noise_forward_ws: impulse responses
+of the whole batch as one split-bf16 matrix-core product (csrc/ddsp_noise_ir.hip) feeding the in-LDS FFT form, against the CPU oracle
+(model/ddsp/filtered_noise.py:7-53) and against the cosine-sum path it replaces.  Tolerance 2e-6 (relative to max(1, |y|)) as for
+every other noise form."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import ddsp_pytorch_amd as ddsp
+from ddsp_pytorch_amd import synthetic as syn
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-6
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def cosine_sums(fn):
+    """Runs fn() with the matrix product switched off (ddsp_noise_set_generic bit 4)."""
+    L = ddsp._lib.lib()
+    assert L.ddsp_noise_set_generic(16) == 0
+    try:
+        return fn()
+    finally:
+        L.ddsp_noise_set_generic(0)
+
+
+@pytest.mark.parametrize("B,T,nf", [(3, 101, 195), (1, 256, 195), (5, 64, 200), (2, 150, 224), (4, 67, 193)])
+def test_matrix_product_form_vs_oracle_and_cosine_sums(B, T, nf):
+    """Frame counts that end inside a 64-frame tile, a 16-frame operand and a frame pair; every band count the product is built for."""
+    rng = np.random.default_rng(B * 1000 + T + nf)
+    Hn = syn.controller_range(rng.standard_normal((B, T, nf), dtype=np.float32))
+    assert ddsp._lib.lib().ddsp_noise_workspace_bytes(B, T, nf, 512) > 0
+    u = rng.random((B, T, 512), dtype=np.float32)
+    y = ddsp.noise_forward(dev(Hn), 512, uniform=dev(u)).cpu().numpy()
+    ref = oracle.noise_forward(Hn, u, 512)
+    scale = max(1.0, float(np.max(np.abs(ref))))
+    assert np.max(np.abs(y - ref)) <= TOL * scale
+    y_sums = cosine_sums(lambda: ddsp.noise_forward(dev(Hn), 512, uniform=dev(u))).cpu().numpy()
+    assert np.max(np.abs(y - y_sums)) <= TOL * scale
+    assert np.max(np.abs(y_sums - ref)) <= TOL * scale
+
+
+def test_matrix_product_form_device_draw_and_accumulate():
+    rng = np.random.default_rng(77)
+    B, T, nf = 2, 140, 195
+    Hn = syn.controller_range(rng.standard_normal((B, T, nf), dtype=np.float32))
+    seed, offset = 4321, (3 << 32) + 5
+    ref = oracle.noise_forward(Hn, None, 512, seed=seed, offset=offset)
+    y = ddsp.noise_forward(dev(Hn), 512, seed=seed, offset=offset).cpu().numpy()
+    assert np.max(np.abs(y - ref)) <= TOL * max(1.0, float(np.max(np.abs(ref))))
+    base = rng.standard_normal((B, T * 512)).astype(np.float32)
+    both = ddsp.noise_forward(dev(Hn), 512, seed=seed, offset=offset, out=dev(base), accumulate=True).cpu().numpy()
+    assert np.max(np.abs(both - (base + ref))) <= TOL * max(1.0, float(np.max(np.abs(ref)))) + 1e-6
+    counter = torch.tensor([offset], dtype=torch.int64, device="cuda")
+    y_c = ddsp.noise_forward(dev(Hn), 512, seed=seed, counter=counter).cpu().numpy()
+    assert np.array_equal(y_c, y)
+
+
+def test_matrix_product_form_silent_and_unequal_frames():
+    """An all-zero frame comes out as exact zeros (its pair partner's rounding does not leak in); a frame 1e6 times quieter than its
+    partner keeps its RELATIVE accuracy (power-of-two equalisers from the product kernel's max |H| column)."""
+    rng = np.random.default_rng(5)
+    B, T, nf = 1, 260, 195
+    Hn = syn.controller_range(rng.standard_normal((B, T, nf), dtype=np.float32))
+    Hn[0, 10] = 0.0
+    Hn[0, 21] *= 1e-6
+    u = rng.random((B, T, 512), dtype=np.float32)
+    y = ddsp.noise_forward(dev(Hn), 512, uniform=dev(u)).cpu().numpy().reshape(T, 512)
+    ref = oracle.noise_forward(Hn, u, 512).reshape(T, 512)
+    assert not y[10].any()
+    assert np.max(np.abs(y[21] - ref[21])) <= TOL * max(1e-6, float(np.max(np.abs(ref[21]))))
+    assert np.max(np.abs(y - ref)) <= TOL * max(1.0, float(np.max(np.abs(ref))))
+
+
+def test_workspace_contract():
+    """ddsp_noise_workspace_bytes is 0 where no form uses one; ddsp_noise_forward_ws without a workspace is ddsp_noise_forward."""
+    L = ddsp._lib.lib()
+    for B, T, nf, hop in ((512, 375, 257, 512), (512, 500, 65, 128), (1, 100, 195, 512), (1, 4, 195, 512), (8, 64, 195, 256), (0, 5, 195, 512)):
+        assert L.ddsp_noise_workspace_bytes(B, T, nf, hop) == 0
+    need = L.ddsp_noise_workspace_bytes(2, 200, 195, 512)
+    assert need >= 400 * 196 * 4
+    rng = np.random.default_rng(9)
+    Hn = dev(syn.controller_range(rng.standard_normal((2, 200, 195), dtype=np.float32)))
+    y0 = torch.empty(2, 200 * 512, device="cuda")
+    y1 = torch.empty_like(y0)
+    s = torch.cuda.current_stream().cuda_stream
+    assert L.ddsp_noise_forward(Hn.data_ptr(), None, y0.data_ptr(), 2, 200, 195, 512, 11, 0, 0, s) == 0
+    assert L.ddsp_noise_forward_ws(Hn.data_ptr(), None, y1.data_ptr(), 2, 200, 195, 512, 11, 0, None, 0, None, 0, s) == 0
+    assert torch.equal(y0, y1)
+    small = torch.empty(need - 16, dtype=torch.uint8, device="cuda")      # too small: the same fallback, no overrun
+    assert L.ddsp_noise_forward_ws(Hn.data_ptr(), None, y1.data_ptr(), 2, 200, 195, 512, 11, 0, None, 0, small.data_ptr(),
+                                   ctypes.c_size_t(need - 16), s) == 0
+    assert torch.equal(y0, y1)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    assert L.ddsp_noise_forward_ws(Hn.data_ptr(), None, y1.data_ptr(), 2, 200, 195, 512, 11, 0, None, 0, ws.data_ptr(),
+                                   ctypes.c_size_t(need), s) == 0
+    assert float((y0 - y1).abs().max()) <= TOL * max(1.0, float(y0.abs().max()))
+
+
+def test_matrix_product_form_in_a_captured_graph():
+    """The three launches (cosine operand, product, FFT form) and torch's workspace allocation replay as one hipGraph."""
+    rng = np.random.default_rng(31)
+    Hn = dev(syn.controller_range(rng.standard_normal((2, 130, 195), dtype=np.float32)))
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+    eager = ddsp.noise_forward(Hn, 512, seed=3, counter=counter).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ddsp.noise_forward(Hn, 512, seed=3, counter=counter)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y = ddsp.noise_forward(Hn, 512, seed=3, counter=counter)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, eager)

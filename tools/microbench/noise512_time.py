@@ -22,9 +22,11 @@ def run(H, y, acc, reps=10):
     for i in range(reps):
         ddsp.noise_forward(H, 512, seed=1, offset=i << 32, out=y, accumulate=acc)
     torch.cuda.synchronize()
-    ms = [m for n, m in ddsp._lib.profile_read() if n == "noise_frame"]
+    rec = ddsp._lib.profile_read()
     ddsp._lib.profile_enable(0)
-    return round(float(np.mean(ms)), 4)
+    ms = [m for n, m in rec if n == "noise_frame"]
+    ir = [m for n, m in rec if n == "noise_impulse_responses"]      # (195 bands: the matrix product ahead of the FFT form)
+    return round(float(np.mean(ms)) + (float(np.mean(ir)) if ir else 0.0), 4)
 
 
 if __name__ == "__main__":
@@ -34,5 +36,9 @@ if __name__ == "__main__":
         H = torch.from_numpy(syn.controller_range(rng.standard_normal((512, 375, F), dtype=np.float32))).cuda()
         y = torch.zeros(512, 375 * 512, device="cuda")
         out[f"F{F}"] = {"acc_ms": [run(H, y, True) for _ in range(3)], "plain_ms": [run(H, y, False) for _ in range(3)]}
+        if F == 195:      # the cosine-sum path the matrix product replaced (ddsp_noise_set_generic bit 4)
+            ddsp._lib.lib().ddsp_noise_set_generic(16)
+            out["F195_cosine_sums"] = {"acc_ms": [run(H, y, True) for _ in range(3)], "plain_ms": [run(H, y, False) for _ in range(3)]}
+            ddsp._lib.lib().ddsp_noise_set_generic(0)
         del H, y
     print(json.dumps(out))
