@@ -69,6 +69,8 @@ def lib():
     L.ddsp_noise_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.ddsp_noise_forward_ws.restype = i32
     L.ddsp_noise_forward_ws.argtypes = [vp, vp, vp, i32, i32, i32, i32, u64, u64, vp, i32, vp, ctypes.c_size_t, vp]
+    L.ddsp_noise_backward_ws.restype = i32
+    L.ddsp_noise_backward_ws.argtypes = [vp, vp, vp, i32, i32, i32, i32, u64, u64, vp, vp, ctypes.c_size_t, vp]
     L.ddsp_osc_set_tiling.restype = i32
     L.ddsp_osc_set_tiling.argtypes = [i32]
     L.ddsp_osc_backward_scratch_bytes.restype = ctypes.c_size_t
@@ -161,7 +163,7 @@ def lib():
     return L
 
 
-EXPORTS = ("ddsp_hip_abi_version", "ddsp_test_hooks_enabled", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_osc_forward_ex", "ddsp_osc_set_path", "ddsp_osc_plan", "ddsp_osc_clock", "ddsp_noise_forward", "ddsp_noise_forward_counter", "ddsp_noise_workspace_bytes", "ddsp_noise_forward_ws",
+EXPORTS = ("ddsp_hip_abi_version", "ddsp_test_hooks_enabled", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_osc_forward_ex", "ddsp_osc_set_path", "ddsp_osc_plan", "ddsp_osc_clock", "ddsp_noise_forward", "ddsp_noise_forward_counter", "ddsp_noise_workspace_bytes", "ddsp_noise_forward_ws", "ddsp_noise_backward_ws",
            "ddsp_osc_backward_scratch_bytes", "ddsp_osc_backward", "ddsp_noise_backward", "ddsp_noise_backward_counter",
            "ddsp_osc_set_tiling", "ddsp_noise_set_generic", "ddsp_profile_enable", "ddsp_profile_read",
            "ddsp_gru_scratch_bytes", "ddsp_gru_max_batch", "ddsp_gru_forward", "ddsp_gru_backward", "ddsp_gru_forward_bf16", "ddsp_gru_backward_bf16", "ddsp_gru_status", "ddsp_gru_set_mode", "ddsp_gru_set_fault_step",

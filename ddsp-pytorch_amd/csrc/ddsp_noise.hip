@@ -685,23 +685,32 @@ extern "C" int ddsp_noise_set_generic(int on)
 }
 
 static int noise_backward_impl(const float *grad_y, const float *uniform, float *grad_H, int B, int T, int F, int hop,
-                               uint64_t seed, uint64_t offset, const uint64_t *offset_dev, void *stream);
+                               uint64_t seed, uint64_t offset, const uint64_t *offset_dev, void *workspace, size_t workspace_bytes,
+                               void *stream);
 
 extern "C" int ddsp_noise_backward(const float *grad_y, const float *uniform, float *grad_H, int B, int T, int F, int hop,
                                    uint64_t seed, uint64_t offset, void *stream)
 {
-    return noise_backward_impl(grad_y, uniform, grad_H, B, T, F, hop, seed, offset, nullptr, stream);
+    return noise_backward_impl(grad_y, uniform, grad_H, B, T, F, hop, seed, offset, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int ddsp_noise_backward_counter(const float *grad_y, float *grad_H, int B, int T, int F, int hop, uint64_t seed,
                                            const uint64_t *counter_dev, void *stream)
 {
     if (!counter_dev) return DDSP_EINVAL;
-    return noise_backward_impl(grad_y, nullptr, grad_H, B, T, F, hop, seed, 0, counter_dev, stream);
+    return noise_backward_impl(grad_y, nullptr, grad_H, B, T, F, hop, seed, 0, counter_dev, nullptr, 0, stream);
+}
+
+extern "C" int ddsp_noise_backward_ws(const float *grad_y, const float *uniform, float *grad_H, int B, int T, int F, int hop, uint64_t seed,
+                                      uint64_t offset, const uint64_t *counter_dev, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (uniform && counter_dev) return DDSP_EINVAL;
+    return noise_backward_impl(grad_y, uniform, grad_H, B, T, F, hop, seed, offset, counter_dev, workspace, workspace_bytes, stream);
 }
 
 static int noise_backward_impl(const float *grad_y, const float *uniform, float *grad_H, int B, int T, int F, int hop,
-                               uint64_t seed, uint64_t offset, const uint64_t *offset_dev, void *stream)
+                               uint64_t seed, uint64_t offset, const uint64_t *offset_dev, void *workspace, size_t workspace_bytes,
+                               void *stream)
 {
     if (B == 0) return 0;
     if (!grad_y || !grad_H || B < 0 || T <= 0 || F < 2 || hop <= 0) return DDSP_EINVAL;
@@ -713,7 +722,12 @@ static int noise_backward_impl(const float *grad_y, const float *uniform, float 
     hipStream_t s = (hipStream_t)stream;
     if (!(g_force_generic.load(std::memory_order_relaxed) & 3)) {    // hop 512: correlation in the in-LDS FFT form (mode bits 0 / 1 keep the direct forms)
         hipError_t fe = hipSuccess;
-        if (launch_noise_fft_backward(grad_y, uniform, grad_H, B, T, F, hop, seed, offset, offset_dev, s, &fe)) return (int)fe;
+        // (a workspace is used only by the shapes of ddsp_noise_workspace_bytes; mode bit 4 keeps the direct kernels there)
+        const bool ws_ok = workspace && !(g_force_generic.load(std::memory_order_relaxed) & 16) && ir_product_shape(F, hop) &&
+                           (long)B * T >= kIrProductMinFrames && workspace_bytes >= ir_workspace_bytes((long)B * T, F) &&
+                           ((uintptr_t)workspace % 16) == 0;
+        if (launch_noise_fft_backward(grad_y, uniform, grad_H, B, T, F, hop, seed, offset, offset_dev, ws_ok ? workspace : nullptr, s, &fe))
+            return (int)fe;
     }
     const int lpf_log = pick_bwd_lpf_log(F, hop);
     p.lpf_log = lpf_log < 0 ? 0 : lpf_log;

@@ -47,10 +47,11 @@ __device__ __forceinline__ float philox_to_sample(uint32_t r) { return __fmaf_rn
 // returns false (and launches nothing) otherwise.  *err receives the launch status.
 bool launch_noise_fft(const NoiseParams &p, hipStream_t s, bool force_fft, hipError_t *err);
 
-// Backward of the noise path in the in-LDS FFT form (hop 512, impulse response not cropped); returns false (and launches
-// nothing) for other shapes.  *err receives the launch status.
+// Backward of the noise path in the in-LDS FFT form (hop 512; 257 bands, or -- given a workspace of ir_workspace_bytes -- the
+// shapes of ir_product_shape, whose dH step is then one matrix product); returns false (and launches nothing) for other shapes.
+// *err receives the launch status.
 bool launch_noise_fft_backward(const float *grad_y, const float *uniform, float *grad_H, int B, int T, int F, int hop, uint64_t seed,
-                               uint64_t offset, const uint64_t *offset_dev, hipStream_t s, hipError_t *err);
+                               uint64_t offset, const uint64_t *offset_dev, void *workspace, hipStream_t s, hipError_t *err);
 
 // Impulse responses as one split-bf16 matrix product for the whole batch (ddsp_noise_ir.hip): the shapes it is built for, the
 // workspace it needs (| cosine operand | z rows |), and the launch -> the z rows inside the workspace (nullptr: launch error in *err).
@@ -58,6 +59,10 @@ bool ir_product_shape(int F, int hop);
 int ir_row_stride(int F);
 size_t ir_workspace_bytes(long frames, int F);
 const float *launch_noise_ir(const float *Hmag, long frames, int F, void *workspace, hipStream_t s, hipError_t *err);
+float *ir_rows(void *workspace, int F);
+hipError_t launch_ir_table(void *workspace, int F, int transpose, hipStream_t s);
+hipError_t launch_ir_product(const float *in, int in_stride, float *out, int out_stride, int out_cols, float *maxabs, long frames, int F,
+                             const void *workspace, hipStream_t s);
 
 // Launches the wavefront-private hop-128 / 65-band form (ddsp_noise_wave.hip) on the leading whole groups of 16 frames when the
 // shape is the one it is built for.  Returns the number of frames it took (0: not its shape, nothing launched; the caller runs

@@ -417,11 +417,18 @@ struct NoiseFftBwdParams {
     const float *g;      // [B, T*R] upstream gradient
     const float *u;      // [B, T, R] the forward's uniform draw (nullable -> Philox from seed / offset, as the forward)
     float *gH;           // [B, T, F]
+    float *dz;           // ZOUT: the gradient of the impulse responses' unique taps, [B*T][zs], n = 0 .. S/2 (ddsp_noise_ir.hip finishes)
+    int zs;
     int B, T, F, S;
     uint64_t seed, offset;
     const uint64_t *offset_dev;
 };
 
+// ZOUT (S < R: 195 bands, the reference's default): steps 1-3 as above, then dz[n] = dk[n] w(n + S/2) + dk[R - n] w(S/2 - n), n = 0 .. S/2
+// (the adjoint of the forward's roll / window / pad / roll, filtered_noise.py:12-20), written -- with the 1/S of the inverse
+// transform and the row's 2^e -- to the workspace; dH = dz C^T is then ONE matrix-core product for the whole batch (ddsp_noise_ir.hip)
+// instead of F x S/2 cosine sums per frame.
+template <bool ZOUT>
 __global__ void __launch_bounds__(64, 2) noise_fft_bwd_kernel(NoiseFftBwdParams p, long npairs)
 {
     constexpr int R1 = 16, N = 64 * R1, R = N / 2;
@@ -475,7 +482,8 @@ __global__ void __launch_bounds__(64, 2) noise_fft_bwd_kernel(NoiseFftBwdParams 
         for (int e = 0; e < quads / 64; ++e)
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) { ma = fmaxf(ma, fabsf(gcur.a[e][c4])); mb = fmaxf(mb, fabsf(gcur.b[e][c4])); }
-        const FrameScale sca = frame_scale(ma, 1.0f, 1.0f / 512.0f), scb = frame_scale(mb, 1.0f, 1.0f / 512.0f);   // .out: the dH step's 1/S
+        const float invS = 1.0f / (float)p.S;
+        const FrameScale sca = frame_scale(ma, 1.0f, invS), scb = frame_scale(mb, 1.0f, invS);   // .out: the dH step's 1/S
         const float sa = sca.in, sb = scb.in;
 #pragma unroll
         for (int e = 0; e < quads / 64; ++e) {
@@ -540,7 +548,36 @@ __global__ void __launch_bounds__(64, 2) noise_fft_bwd_kernel(NoiseFftBwdParams 
         fft_wave<R1, true, false>(v, tw, bufA, lane);
         constexpr float kScale = 1.0f / (4.0f * (float)N);
 
-        {
+        if constexpr (ZOUT) {
+            // ---- 4'. dk (both frames) through LDS; every lane folds the two wrapped positions of its taps -------------------
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int k3 = 0; k3 < 4; ++k3) bufB[lane + 64 * (d + 2 * k3)] = v[d * 8 + k3];
+            DDSP_WAVE_ORDER();
+            const int S = p.S, half = S >> 1;
+            float *za = p.dz + fa * p.zs, *zb = p.dz + fb * p.zs;
+            const float oa = sca.out * kScale, ob = scb.out * kScale;
+#pragma unroll
+            for (int e = 0; e < R / 128 + 1; ++e) {
+                const int n = lane + 64 * e;
+                if (n <= half) {
+                    float da = 0.0f, db = 0.0f;
+                    if (n < half) {
+                        const float w = 0.5f - 0.5f * cospif((float)(2 * (n + half)) / (float)S);
+                        const cf t = bufB[n];
+                        da = t.x * w; db = t.y * w;
+                    }
+                    if (n > 0) {
+                        const float w = 0.5f - 0.5f * cospif((float)(2 * (half - n)) / (float)S);
+                        const cf t = bufB[R - n];
+                        da = __fmaf_rn(t.x, w, da); db = __fmaf_rn(t.y, w, db);
+                    }
+                    za[n] = da * oa;
+                    zb[n] = db * ob;
+                }
+            }
+        } else {
             // ---- 4. dz[n] = dk[n] window(n), n = lane + 64 (d + 2 k3): exactly input n1 = d + 2 k3 of the 512-point transform
             constexpr float r8 = 0.70710678118654752f;
             const float ck[8] = {1.0f, r8, 0.0f, -r8, -1.0f, -r8, 0.0f, r8}, sk[8] = {0.0f, r8, 1.0f, r8, 0.0f, -r8, -1.0f, -r8};
@@ -631,13 +668,15 @@ bool launch_noise_fft(const NoiseParams &p, hipStream_t s, bool force_fft, hipEr
 }
 
 bool launch_noise_fft_backward(const float *grad_y, const float *uniform, float *grad_H, int B, int T, int F, int hop, uint64_t seed,
-                               uint64_t offset, const uint64_t *offset_dev, hipStream_t s, hipError_t *err)
+                               uint64_t offset, const uint64_t *offset_dev, void *workspace, hipStream_t s, hipError_t *err)
 {
     const int S = 2 * (F - 1);
-    if (hop != 512 || S != hop) return false;                        // other shapes: the direct kernels (see above)
+    const bool zout = workspace && ir_product_shape(F, hop);         // 195 bands: dz to the workspace, dH = dz C^T as one product
+    if (hop != 512 || (S != hop && !zout)) return false;             // other shapes: the direct kernels (see above)
     if (((uintptr_t)grad_y % 16) != 0 || (uniform && ((uintptr_t)uniform % 16) != 0)) return false;
     NoiseFftBwdParams q;
     q.g = grad_y; q.u = uniform; q.gH = grad_H; q.B = B; q.T = T; q.F = F; q.S = S;
+    q.dz = nullptr; q.zs = 0;
     q.seed = seed; q.offset = offset; q.offset_dev = offset_dev;
     const long nframes = (long)B * T, npairs = (nframes + 1) / 2;
     const size_t lds = sizeof(float2) * 2 * buf_elems<16>();
@@ -653,7 +692,18 @@ bool launch_noise_fft_backward(const float *grad_y, const float *uniform, float 
     cus = cached[dev & 63];
     const long resident = (long)cus * 8;                             // 17 KB of LDS each: eight wavefronts per CU
     const long grid = npairs < resident ? npairs : resident;
-    hipLaunchKernelGGL(noise_fft_bwd_kernel, dim3((unsigned)grid), dim3(64), lds, s, q, npairs);
+    if (zout) {
+        q.dz = ir_rows(workspace, F);
+        q.zs = ir_row_stride(F);
+        *err = launch_ir_table(workspace, F, 1, s);
+        if (*err != hipSuccess) return true;
+        hipLaunchKernelGGL(noise_fft_bwd_kernel<true>, dim3((unsigned)grid), dim3(64), lds, s, q, npairs);
+        *err = hipGetLastError();
+        if (*err != hipSuccess) return true;
+        *err = launch_ir_product(q.dz, q.zs, grad_H, F, F, nullptr, nframes, F, workspace, s);
+        return true;
+    }
+    hipLaunchKernelGGL(noise_fft_bwd_kernel<false>, dim3((unsigned)grid), dim3(64), lds, s, q, npairs);
     *err = hipGetLastError();
     return true;
 }

@@ -190,24 +190,42 @@ size_t ir_table_bytes(int F) { return (size_t)((F + 15) / 16) * KT * 3 * 64 * si
 
 size_t ir_workspace_bytes(long frames, int F) { return ir_table_bytes(F) + (size_t)frames * ir_row_stride(F) * sizeof(float); }
 
-// z rows of every frame into the workspace: | table | z [frames][ir_row_stride] |.  Returns the z rows (nullptr on a launch error).
-const float *launch_noise_ir(const float *Hmag, long frames, int F, void *workspace, hipStream_t s, hipError_t *err)
+float *ir_rows(void *workspace, int F) { return reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + ir_table_bytes(F)); }
+
+// The cosine operand into the head of the workspace (transpose: the backward's, bins on the output side).
+hipError_t launch_ir_table(void *workspace, int F, int transpose, hipStream_t s)
 {
-    const int NT = (F + 15) / 16, S = 2 * (F - 1), zs = ir_row_stride(F);
-    bf16x8 *table = reinterpret_cast<bf16x8 *>(workspace);
-    float *z = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + ir_table_bytes(F));
-    const int cus = device_cus(err);
-    if (*err != hipSuccess) return nullptr;
-    const int slot = ddsp_prof::begin(ddsp_prof::NOISE_IR, s);
-    hipLaunchKernelGGL(noise_ir_table_kernel, dim3((unsigned)(NT * KT)), dim3(64), 0, s, table, F, S, NT, 0);
+    const int NT = (F + 15) / 16, S = 2 * (F - 1);
+    hipLaunchKernelGGL(noise_ir_table_kernel, dim3((unsigned)(NT * KT)), dim3(64), 0, s, reinterpret_cast<bf16x8 *>(workspace), F, S, NT, transpose);
+    return hipGetLastError();
+}
+
+// out[frame][o] = sum_i in[frame][i] C[i][o], i, o < F, with the operand launch_ir_table left in the workspace.
+hipError_t launch_ir_product(const float *in, int in_stride, float *out, int out_stride, int out_cols, float *maxabs, long frames, int F,
+                             const void *workspace, hipStream_t s)
+{
+    hipError_t err = hipSuccess;
+    const int cus = device_cus(&err);
+    if (err != hipSuccess) return err;
     IrParams p;
-    p.in = Hmag; p.table = table; p.out = z; p.maxabs = z + 16 * NT; p.frames = frames;
-    p.F = F; p.NT = NT; p.in_stride = F; p.out_stride = zs; p.out_cols = 16 * NT;
+    p.in = in; p.table = reinterpret_cast<const bf16x8 *>(workspace); p.out = out; p.maxabs = maxabs; p.frames = frames;
+    p.F = F; p.NT = (F + 15) / 16; p.in_stride = in_stride; p.out_stride = out_stride; p.out_cols = out_cols;
     const long tiles = (frames + 63) / 64, resident = (long)cus * 2;
     const size_t lds = (size_t)2 * KT * 3 * 64 * sizeof(bf16x8);
     hipLaunchKernelGGL(noise_ir_kernel, dim3((unsigned)(tiles < resident ? tiles : resident)), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+// Forward: z rows (x S) of every frame into the workspace, | table | z [frames][ir_row_stride] |, max |H| of a frame in column
+// 16 NT of its row.  Returns the z rows (nullptr on a launch error).
+const float *launch_noise_ir(const float *Hmag, long frames, int F, void *workspace, hipStream_t s, hipError_t *err)
+{
+    const int NT = (F + 15) / 16, zs = ir_row_stride(F);
+    float *z = ir_rows(workspace, F);
+    const int slot = ddsp_prof::begin(ddsp_prof::NOISE_IR, s);
+    *err = launch_ir_table(workspace, F, 0, s);
+    if (*err == hipSuccess) *err = launch_ir_product(Hmag, F, z, zs, 16 * NT, z + 16 * NT, frames, F, workspace, s);
     ddsp_prof::end(slot, s);
-    *err = hipGetLastError();
     return *err == hipSuccess ? z : nullptr;
 }
 

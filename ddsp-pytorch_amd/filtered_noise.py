@@ -66,7 +66,13 @@ def noise_backward(grad_y, hop: int, n_filters: int, uniform=None, seed: int = 0
         return grad_h
     with torch.cuda.device(grad_y.device):
         stream = torch.cuda.current_stream().cuda_stream
-        if counter is not None:
+        ws_bytes = _lib.lib().ddsp_noise_workspace_bytes(B, T, n_filters, hop)
+        if ws_bytes:
+            ws = torch.empty(ws_bytes, device=grad_y.device, dtype=torch.uint8)
+            rc = _lib.lib().ddsp_noise_backward_ws(grad_y.data_ptr(), None if uniform is None else uniform.data_ptr(), grad_h.data_ptr(),
+                                                   B, T, n_filters, hop, seed, offset, None if counter is None else counter.data_ptr(),
+                                                   ws.data_ptr(), ws_bytes, stream)
+        elif counter is not None:
             rc = _lib.lib().ddsp_noise_backward_counter(grad_y.data_ptr(), grad_h.data_ptr(), B, T, n_filters, hop, seed,
                                                         counter.data_ptr(), stream)
         else:

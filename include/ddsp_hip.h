@@ -104,6 +104,11 @@ size_t ddsp_noise_workspace_bytes(int B, int T, int F, int hop);
 int ddsp_noise_forward_ws(const float *Hmag, const float *uniform, float *y, int B, int T, int F, int hop, uint64_t seed,
                           uint64_t offset, const uint64_t *counter_dev, int accumulate, void *workspace, size_t workspace_bytes,
                           void *stream);
+/* Backward of the same (ddsp_noise_backward / _counter with a workspace of ddsp_noise_workspace_bytes: for the default shape the
+ * correlation runs in the in-LDS FFT form and dH = dz C^T is one matrix-core product, instead of the direct kernels' F x S/2
+ * cosine sums per frame).  The workspace need not be the forward's. */
+int ddsp_noise_backward_ws(const float *grad_y, const float *uniform, float *grad_H, int B, int T, int F, int hop, uint64_t seed,
+                           uint64_t offset, const uint64_t *counter_dev, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Backward of ddsp_osc_forward w.r.t. c and a (autograd of harmonic_oscillator.py:24-62; f0 carries no gradient,

@@ -120,3 +120,51 @@ def test_matrix_product_form_in_a_captured_graph():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(y, eager)
+
+
+@pytest.mark.parametrize("B,T,nf", [(3, 101, 195), (1, 257, 195), (2, 150, 224)])
+def test_matrix_product_backward_vs_reference_autograd_and_direct_kernels(B, T, nf):
+    """dH through the FFT-form correlation + transposed product against (a) torch autograd of the reference's op sequence on the CPU
+    (oracle/torch_restatement.py: filtered_noise.py:7-53) and (b) the direct backward kernels it replaces.  1e-5 relative, as G17."""
+    from oracle import torch_restatement as tr
+    rng = np.random.default_rng(B + T + nf)
+    Hn = syn.controller_range(rng.standard_normal((B, T, nf), dtype=np.float32))
+    u = rng.random((B, T, 512), dtype=np.float32)
+    gy = rng.standard_normal((B, T * 512)).astype(np.float32)
+    gy[:, 512 * 7:512 * 8] *= 1e-5            # a quiet gradient row next to a loud one (the pair's equalisers)
+    Ht = torch.from_numpy(Hn).requires_grad_()
+    (tr.filtered_noise(Ht, 512, torch.from_numpy(u)) * torch.from_numpy(gy)).sum().backward()
+    ref = Ht.grad.numpy()
+    got = ddsp.noise_backward(dev(gy), 512, nf, uniform=dev(u)).cpu().numpy()
+    direct = cosine_sums(lambda: ddsp.noise_backward(dev(gy), 512, nf, uniform=dev(u))).cpu().numpy()
+    scale = max(1.0, float(np.max(np.abs(ref))))
+    assert np.max(np.abs(direct - ref)) <= 1e-5 * scale
+    assert np.max(np.abs(got - ref)) <= 1e-5 * scale
+    quiet = ref[:, 7]
+    assert np.max(np.abs(got[:, 7] - quiet)) <= 1e-5 * max(1e-5, float(np.max(np.abs(quiet))))
+
+
+def test_matrix_product_backward_through_the_module():
+    """FilteredNoise autograd at the default shape: in-kernel draw, the backward regenerates it from the same counter."""
+    rng = np.random.default_rng(3)
+    Hn = syn.controller_range(rng.standard_normal((2, 140, 195), dtype=np.float32))
+
+    class Conf:
+        n_harmonics, sample_rate, hop_length = 1, 44100, 512
+
+    def grad(mode):
+        L = ddsp._lib.lib()
+        assert L.ddsp_noise_set_generic(mode) == 0
+        try:
+            H = dev(Hn).requires_grad_()
+            fn = ddsp.FilteredNoise(Conf, rng="device", seed=5)
+            y = fn({"H": H})
+            (y * y).sum().backward()
+            return y.detach().cpu().numpy(), H.grad.cpu().numpy()
+        finally:
+            L.ddsp_noise_set_generic(0)
+
+    y0, g0 = grad(16)
+    y1, g1 = grad(0)
+    assert np.max(np.abs(y1 - y0)) <= TOL * max(1.0, float(np.max(np.abs(y0))))
+    assert np.max(np.abs(g1 - g0)) <= 1e-5 * max(1.0, float(np.max(np.abs(g0))))
