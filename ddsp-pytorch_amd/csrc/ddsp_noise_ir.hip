@@ -28,6 +28,7 @@ using namespace ddsp_noise;
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));      // a 16-byte load from a 4-byte-aligned address
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct Split { bf16x8 p[3]; };
 // x = hi + mid + lo with every term a bf16: both residuals are exact in fp32 (8 + 8 + 8 significand bits)
@@ -114,10 +115,14 @@ __global__ void __launch_bounds__(256, 2) noise_ir_kernel(IrParams p)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             float v[8];
+            const int i0 = 32 * kt + 8 * mq;
+            if (ok && i0 + 8 <= p.F) {                                // two 16-byte loads (rows start on any 4-byte boundary: F is odd)
+                const v4f_u lo = *reinterpret_cast<const v4f_u *>(row + i0), hi = *reinterpret_cast<const v4f_u *>(row + i0 + 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = 32 * kt + 8 * mq + j;
-                v[j] = (ok && i < p.F) ? row[i] : 0.0f;
+                for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (ok && i0 + j < p.F) ? row[i0 + j] : 0.0f;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) { mx = fmaxf(mx, fabsf(v[j])); split3(v[j], A[kt], j); }
@@ -146,6 +151,9 @@ __global__ void __launch_bounds__(256, 2) noise_ir_kernel(IrParams p)
                 }
             }
             const v4f acc = acc0 + acc1;
+            // the next chunk goes to LDS BEFORE this tile's stores are issued: the wait for its loads then covers only stores that are
+            // a whole chunk old (vector-memory operations retire in order: behind fresh stores it was a full HBM write latency per chunk)
+            park(buf ^ 1, pre);
             // D[m = 4 (lane >> 4) + r][o = lane & 15]
             const int o = 16 * nt + mi;
 #pragma unroll
@@ -153,7 +161,6 @@ __global__ void __launch_bounds__(256, 2) noise_ir_kernel(IrParams p)
                 const long f = f0 + 4 * mq + r;
                 if (f < p.frames && o < p.out_cols) p.out[f * (long)p.out_stride + o] = acc[r];
             }
-            park(buf ^ 1, pre);
             __syncthreads();
             buf ^= 1;
         }
@@ -210,7 +217,10 @@ hipError_t launch_ir_product(const float *in, int in_stride, float *out, int out
     IrParams p;
     p.in = in; p.table = reinterpret_cast<const bf16x8 *>(workspace); p.out = out; p.maxabs = maxabs; p.frames = frames;
     p.F = F; p.NT = (F + 15) / 16; p.in_stride = in_stride; p.out_stride = out_stride; p.out_cols = out_cols;
-    const long tiles = (frames + 63) / 64, resident = (long)cus * 2;
+#ifndef DDSP_IR_WG_PER_CU
+#define DDSP_IR_WG_PER_CU 3
+#endif
+    const long tiles = (frames + 63) / 64, resident = (long)cus * DDSP_IR_WG_PER_CU;
     const size_t lds = (size_t)2 * KT * 3 * 64 * sizeof(bf16x8);
     hipLaunchKernelGGL(noise_ir_kernel, dim3((unsigned)(tiles < resident ? tiles : resident)), dim3(256), lds, s, p);
     return hipGetLastError();
