@@ -61,7 +61,7 @@ size_t ir_workspace_bytes(long frames, int F);
 const float *launch_noise_ir(const float *Hmag, long frames, int F, void *workspace, hipStream_t s, hipError_t *err);
 float *ir_rows(void *workspace, int F);
 hipError_t launch_ir_table(void *workspace, int F, int transpose, hipStream_t s);
-hipError_t launch_ir_product(const float *in, int in_stride, float *out, int out_stride, int out_cols, float *maxabs, long frames, int F,
+hipError_t launch_ir_product(const float *in, int in_stride, float *out, int out_stride, float *maxabs, long frames, int F, int transpose,
                              const void *workspace, hipStream_t s);
 
 // Launches the wavefront-private hop-128 / 65-band form (ddsp_noise_wave.hip) on the leading whole groups of 16 frames when the

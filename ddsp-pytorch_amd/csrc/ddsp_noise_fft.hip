@@ -700,7 +700,7 @@ bool launch_noise_fft_backward(const float *grad_y, const float *uniform, float 
         hipLaunchKernelGGL(noise_fft_bwd_kernel<true>, dim3((unsigned)grid), dim3(64), lds, s, q, npairs);
         *err = hipGetLastError();
         if (*err != hipSuccess) return true;
-        *err = launch_ir_product(q.dz, q.zs, grad_H, F, F, nullptr, nframes, F, workspace, s);
+        *err = launch_ir_product(q.dz, q.zs, grad_H, F, nullptr, nframes, F, 1, workspace, s);
         return true;
     }
     hipLaunchKernelGGL(noise_fft_bwd_kernel<false>, dim3((unsigned)grid), dim3(64), lds, s, q, npairs);
