@@ -107,7 +107,7 @@ def test_chunk_boundaries_anywhere_in_a_segment(lib, chunk_len, monkeypatch):
 
 def test_chunked_declined_chunks_are_repaired_exactly(lib):
     # phases beyond the fast modulo's exact range (1e7 rad), negative f0 and a NaN f0: the fast kernel declines those wave
-    # tasks and the exact kernel redoes them; masked harmonics still accumulate phase
+    # tasks and walks them a second time with the exact modulo; masked harmonics still accumulate phase
     rng = np.random.default_rng(5)
     B, T, H, hop, sr = 4, 300, 100, 512, 8000
     f0 = rng.uniform(30.0, 39.0, (B, T, 1)).astype(np.float32)
