@@ -110,13 +110,18 @@ def time_config(shape, seed, steps, warmup, f0_kind="all_live", noise_seed=7):
     settled = settle_clock(step, 0)
     for i in range(warmup):
         y = step(settled + i)
-    ddsp._lib.profile_enable(8 * steps + 16)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
         y = step(settled + warmup + i)
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / steps
+    # per-kernel averages from `steps` MORE steps with an event pair around every launch (a pair costs the stream ~4 us, 12 % of
+    # a cfg2 step: kept out of the timed region above)
+    ddsp._lib.profile_enable(8 * steps + 16)
+    for i in range(steps):
+        y = step(settled + warmup + steps + i)
+    torch.cuda.synchronize()
     rec = {}
     for name, ms in ddsp._lib.profile_read():
         rec.setdefault(name, []).append(ms)
@@ -571,10 +576,12 @@ def main():
             torch.cuda.synchronize()
 
     def timed_pass(first):
-        """W untimed steps, then exactly K steps between two fences -> (seconds, per-launch kernel records, last output)."""
+        """W untimed steps, then exactly K steps between two fences -> (seconds, per-launch kernel records, last output).  Inside the
+        timed region only the DOMINANT kernel (the oscillator's synth launch: `roofline`) carries HIP events: an event pair costs the
+        stream ~4 us, and pairs around all four launches of a step cost the headline 2.2 % (1.366 -> 1.336 ms same box)."""
         for i in range(args.warmup):
             y = step(first + i)
-        ddsp._lib.profile_enable(8 * args.steps + 16)
+        ddsp._lib.profile_enable(2 * args.steps + 16, only=["osc_frame_synth"])
         fence()
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -597,6 +604,13 @@ def main():
     elapsed, records, y = timed_pass(done)
     timed_first_launch = done + args.warmup       # index (from 0) of the first timed launch of each kernel in this process
     assert bool(torch.isfinite(y).all()), "non-finite audio"
+    # the other kernels' averages: K more steps right after the timed region, an event pair around every launch
+    ddsp._lib.profile_enable(8 * args.steps + 16)
+    for i in range(args.steps):
+        y = step(done + args.warmup + args.steps + i)
+    torch.cuda.synchronize()
+    breakdown = ddsp._lib.profile_read()
+    ddsp._lib.profile_enable(0)
     own_elapsed = elapsed
     if dist is not None:
         tmax = torch.tensor([elapsed, idle_elapsed], device="cuda", dtype=torch.float64)
@@ -606,9 +620,12 @@ def main():
     for name, ms in idle_records:
         idle_kernel.setdefault(name, []).append(ms)
     per_kernel = {}
-    for name, ms in records:
+    for name, ms in breakdown:
+        if name != "osc_frame_synth":
+            per_kernel.setdefault(name, []).append(ms)
+    for name, ms in records:                       # (the timed region's own: the synth kernel)
         per_kernel.setdefault(name, []).append(ms)
-    kern_ms = {k: float(np.mean(v)) for k, v in per_kernel.items()}
+    kern_ms = {k: float(np.mean(per_kernel[k])) for k in KERNELS if k in per_kernel}
     # every rank's own clock and per-kernel averages, gathered so that the first multi-GPU run diagnoses itself: a slow rank
     # (clock, thermal, a noisy neighbour on its XCDs) shows up by index instead of hiding inside the MAX
     diag = gather_rows(dist, [1e3 * own_elapsed / args.steps] + [kern_ms.get(k, float("nan")) for k in KERNELS], world, rank)
@@ -711,6 +728,7 @@ def main():
                                                   "frac": launch_samples * noise_macs / (noise_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS,
                                                   "frac_at_clock": launch_samples * noise_macs / (noise_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS * at_clock if at_clock else None}}},
             "kernel_ms": kern_ms,
+            "kernel_ms_source": "osc_frame_synth: HIP events inside the timed region; the others: K more steps right after it",
             "per_rank_ms": [float(v) for v in diag[:, 0]],
             "per_rank_kernel_ms": {k: [float(v) for v in diag[:, 1 + j]] for j, k in enumerate(KERNELS)},
             "slowest_rank": int(np.argmax(diag[:, 0])),

@@ -24,6 +24,7 @@ std::mutex g_mu;
 std::vector<Record> g_pool;  // created by ddsp_profile_enable
 int g_used = 0;
 bool g_on = false;
+unsigned g_select = ~0u;     // ddsp_profile_select: bit i = record kernel id i
 }  // namespace
 
 namespace ddsp_prof {
@@ -31,6 +32,7 @@ int begin(int kernel_id, hipStream_t s)
 {
     if (!g_on) return -1;
     std::lock_guard<std::mutex> lk(g_mu);
+    if (!((g_select >> (kernel_id & 31)) & 1u)) return -1;
     if (g_used >= (int)g_pool.size()) return -1;
     const int slot = g_used++;
     g_pool[slot].kernel_id = kernel_id;
@@ -59,6 +61,13 @@ extern "C" int ddsp_profile_enable(int capacity)
         if (e != hipSuccess) { g_pool.clear(); return (int)e; }
     }
     g_on = true;
+    return 0;
+}
+
+extern "C" int ddsp_profile_select(unsigned kernel_mask)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_select = kernel_mask ? kernel_mask : ~0u;
     return 0;
 }
 

@@ -166,9 +166,13 @@ int ddsp_noise_set_generic(int on);
  *                                  pair around every kernel launch; capacity <= 0: stop and free them.
  *   ddsp_profile_read(ids, ms, cap) HOST arrays; waits for the recorded events, returns how many records were
  *                                  written (kernel id: 1 frame totals, 2 superblock scan, 3 synth, 4 noise;
- *                                  elapsed milliseconds) and resets the pool.  Never called from a launch path.
+ *                                  5 the 195-band noise product; elapsed milliseconds) and resets the pool.  Never called
+ *                                  from a launch path.
+ *   ddsp_profile_select(mask)      record only the kernels whose id bit is set (0: all, the default).  An event pair costs the
+ *                                  stream ~4 us: bench.py records only the dominant kernel inside its timed region.
  */
 int ddsp_profile_enable(int capacity);
+int ddsp_profile_select(unsigned kernel_mask);
 int ddsp_profile_read(int *kernel_ids, float *ms, int cap);
 
 /*

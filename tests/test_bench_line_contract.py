@@ -41,7 +41,9 @@ def test_line_is_self_consistent():
     assert 1.5 < d["clock_ghz"] < 2.6
     idle = d["clock_settle"]["from_idle"]
     assert idle["ms_per_step"] > 0 and d["clock_settle"]["continuous_load_ms_before_warmup"] >= 60.0
-    assert sum(d["kernel_ms"].values()) <= d["ms_per_step"]
+    # (only the synth kernel is timed inside the timed region; the others come from K more steps with events around every launch,
+    #  which slow the stream a little: their sum may exceed the step by that much)
+    assert d["kernel_ms"]["osc_frame_synth"] < d["ms_per_step"] and abs(sum(d["kernel_ms"].values()) / d["ms_per_step"] - 1.0) < 0.06
     for k in ("cfg1", "cfg2", "cfg3", "musical", "live_callback", "train_step"):
         assert k in d["configs"], k
 
