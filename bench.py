@@ -493,6 +493,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not measure roofline.traffic with two rocprofv3 child passes after the timed region (N = 1); use the committed profile")
+    ap.add_argument("--no-calibrate", action="store_true",
+                    help="keep the noise kernel's default residency (4 wavefronts per CU) instead of measuring this box first")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary figures (cfg1, cfg2, cfg3, musical f0, live callback, training step) timed after the headline at N = 1")
     ap.add_argument("--mode", default="synth", choices=["synth", "train"],
@@ -592,6 +594,17 @@ def main():
         ddsp._lib.profile_enable(0)
         return el, rec, y
 
+    # (0) one-time autotuning of the noise kernel's residency on THIS box (the count of its wavefronts per CU at which the chip's power
+    # management starts to drop the clock differs between boxes: DESIGN.md section 5), with this very step; then idle for half a second
+    cal_i = [1 << 20]
+
+    def cal_step():
+        step(cal_i[0])
+        cal_i[0] += 1
+
+    residency = ddsp.calibrate_noise_residency(cal_step) if not args.no_calibrate else None
+    torch.cuda.synchronize()
+    time.sleep(0.5)
     # (1) the same W + K from an idle GPU, reported as `from_idle`; (2) more of the same step until the GPU has been under load for
     # SETTLE_MS; (3) W + K again = the line's `value`: the sustained rate of the path, not the clock governor's ramp (settle_clock)
     t_settle = time.perf_counter()
@@ -684,6 +697,10 @@ def main():
                        "step": "OscillatorBank.forward + FilteredNoise.forward accumulated (harmonics + noise)",
                        "arithmetic": "fp32 with an fp64 phase accumulator (torch CPU cumsum semantics)"},
             "samples_per_sec_per_gpu": samples_per_step * args.steps / elapsed / world,
+            "noise_residency": {"waves_per_cu": ddsp._lib.lib().ddsp_noise_get_residency(), "library_default": 4,
+                                "calibration_ms_per_step": residency["ms_per_step"] if residency else None,
+                                "note": "ddsp_pytorch_amd.calibrate_noise_residency with this step, before everything else (0.7 s, untimed): "
+                                        "wavefronts per CU of the hop-128 noise kernel; above a box-dependent count the chip drops its clock"},
             "clock_settle": {"note": "the timed region above follows >= %.0f ms of the same step back to back: the clock governor needs ~25 ms "
                                      "of load to reach its sustained clock, W = %d warm-up steps are %.0f ms.  `from_idle` is the same W + K "
                                      "started on an idle GPU (the first thing this process ran), max over ranks" % (

@@ -85,6 +85,10 @@ def lib():
     L.ddsp_noise_set_generic.argtypes = [i32]
     L.ddsp_profile_enable.restype = i32
     L.ddsp_profile_enable.argtypes = [i32]
+    L.ddsp_noise_set_residency.restype = i32
+    L.ddsp_noise_set_residency.argtypes = [i32]
+    L.ddsp_noise_get_residency.restype = i32
+    L.ddsp_noise_get_residency.argtypes = []
     L.ddsp_profile_select.restype = i32
     L.ddsp_profile_select.argtypes = [ctypes.c_uint]
     L.ddsp_profile_read.restype = i32
@@ -165,7 +169,7 @@ def lib():
     return L
 
 
-EXPORTS = ("ddsp_hip_abi_version", "ddsp_test_hooks_enabled", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_osc_forward_ex", "ddsp_osc_set_path", "ddsp_osc_plan", "ddsp_osc_clock", "ddsp_noise_forward", "ddsp_noise_forward_counter", "ddsp_noise_workspace_bytes", "ddsp_noise_forward_ws", "ddsp_noise_backward_ws", "ddsp_profile_select",
+EXPORTS = ("ddsp_hip_abi_version", "ddsp_test_hooks_enabled", "ddsp_osc_scratch_bytes", "ddsp_osc_forward", "ddsp_osc_forward_ex", "ddsp_osc_set_path", "ddsp_osc_plan", "ddsp_osc_clock", "ddsp_noise_forward", "ddsp_noise_forward_counter", "ddsp_noise_workspace_bytes", "ddsp_noise_forward_ws", "ddsp_noise_backward_ws", "ddsp_profile_select", "ddsp_noise_set_residency", "ddsp_noise_get_residency",
            "ddsp_osc_backward_scratch_bytes", "ddsp_osc_backward", "ddsp_noise_backward", "ddsp_noise_backward_counter",
            "ddsp_osc_set_tiling", "ddsp_noise_set_generic", "ddsp_profile_enable", "ddsp_profile_read",
            "ddsp_gru_scratch_bytes", "ddsp_gru_max_batch", "ddsp_gru_forward", "ddsp_gru_backward", "ddsp_gru_forward_bf16", "ddsp_gru_backward_bf16", "ddsp_gru_status", "ddsp_gru_set_mode", "ddsp_gru_set_fault_step",

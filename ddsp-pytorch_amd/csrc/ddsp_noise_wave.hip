@@ -2,7 +2,7 @@
 // Same arithmetic contract as ddsp_noise.hip (model/ddsp/filtered_noise.py:7-53); different organisation (noise section):
 //
 //   * ONE WAVEFRONT owns a group of 16 frames at a time and shares nothing with other wavefronts: no workgroup barrier anywhere
-//     (64-thread workgroups, 17.4 KB of LDS each, FIVE per CU -- launch_noise_wave says why not eight; LDS operations of one wavefront execute in order,
+//     (64-thread workgroups, 17.4 KB of LDS each, four per CU by default -- launch_noise_wave says why not eight; LDS operations of one wavefront execute in order,
 //     which is all the hand-offs between the stages need).  Persistent: a wavefront walks groups g, g + grid, ...
 //   * software pipeline over the groups, written so that every global access sits in straight-line code (the compiler's
 //     `s_waitcnt vmcnt` are then exact counts, not drains): the NEXT group's filter magnitudes (16 x 65 contiguous floats) are
@@ -33,6 +33,8 @@
 // Only whole groups: launch_noise_wave() hands a remainder of fewer than 16 frames to the batched kernel (same Philox counters).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <atomic>
 
 #include "ddsp_hip.h"
 #include "ddsp_internal.h"
@@ -394,6 +396,25 @@ __global__ void __launch_bounds__(64, 2) noise_wave_kernel(NoiseParams p, long n
 
 }  // namespace
 
+namespace {
+constexpr int kDefaultWavesPerCu = 4;
+std::atomic<int> g_residency{0};      // ddsp_noise_set_residency: wavefronts per CU of noise_wave_kernel (0: the default)
+}  // namespace
+
+// Production tuning knob (not a test hook): wavefronts per CU, 1..8, of the hop-128 noise kernel's persistent grid; 0 restores the
+// default.  Results do not depend on it (a group of 16 frames is computed by one wavefront either way).
+extern "C" int ddsp_noise_set_residency(int waves_per_cu)
+{
+    if (waves_per_cu < 0 || waves_per_cu > 8) return DDSP_EINVAL;
+    g_residency.store(waves_per_cu, std::memory_order_relaxed);
+    return 0;
+}
+extern "C" int ddsp_noise_get_residency(void)
+{
+    const int v = g_residency.load(std::memory_order_relaxed);
+    return v >= 1 && v <= 8 ? v : kDefaultWavesPerCu;
+}
+
 namespace ddsp_noise {
 
 long launch_noise_wave(const NoiseParams &p, hipStream_t s, hipError_t *err)
@@ -414,16 +435,16 @@ long launch_noise_wave(const NoiseParams &p, hipStream_t s, hipError_t *err)
     }
     cus = cached[dev & 63];
     constexpr size_t lds = sizeof(float) * kLdsFloats;
-    // FIVE wavefronts per CU (17.4 KB of LDS each), not the eight that fit two per SIMD: at eight, this kernel's FMA + LDS + HBM
-    // activity makes the chip's power management drop the shader clock (2.41 -> ~2.14 GHz; it takes ~25 ms of load to come back), so
-    // the oscillator's kernels of the NEXT step pay 0.15 ms for the 0.02 ms saved here.  Where the clock starts to give differs
-    // between boxes (below 8 on one, below 6 on another); five keeps it within 1 % of the oscillator-only clock on both and costs
-    // this kernel 0.02-0.03 ms (profiles/r04_clock_ramp.txt; tools/microbench/noise_residency_sweep.sh)
-#ifndef DDSP_NOISE_WAVES_PER_CU
-#define DDSP_NOISE_WAVES_PER_CU 5
-#endif
+    // FOUR wavefronts per CU by default (17.4 KB of LDS each), not the eight that fit two per SIMD: at eight, this kernel's FMA + LDS +
+    // HBM activity makes the chip's power management drop the shader clock (2.41 -> ~2.1 GHz; it takes ~25 ms of load to come back), so
+    // the oscillator's kernels of the NEXT step pay 0.15 ms for the 0.04 ms saved here.  Where the clock gives way differs between
+    // boxes of the same model (below 8, below 6, below 5 wavefronts per CU on the three kinds measured); one wavefront per SIMD held it
+    // on all of them.  ddsp_noise_set_residency lets a caller that has measured ITS box take more (ddsp_pytorch_amd.
+    // calibrate_noise_residency does the measuring; profiles/r04_clock_ramp.txt, tools/microbench/noise_residency_sweep.sh).
+    const int asked = g_residency.load(std::memory_order_relaxed);
+    const long per_cu = asked >= 1 && asked <= 8 ? asked : kDefaultWavesPerCu;
     // (a launch of at most one group per wavefront at eight per CU -- cfg2, the training step: ~20 us -- is over before the trip)
-    long resident = ngroups <= (long)cus * 8 ? (long)cus * 8 : (long)cus * DDSP_NOISE_WAVES_PER_CU;
+    long resident = ngroups <= (long)cus * 8 ? (long)cus * 8 : (long)cus * per_cu;
     // tuning experiments (DDSP_TEST_HOOKS=1 processes only; read once): wavefronts per CU
     static const long env_waves = [] { const char *ev = getenv("DDSP_NOISE_WAVES"); return (ev && ddsp_hooks_on()) ? atol(ev) : 0L; }();
     if (env_waves > 0 && env_waves <= 8) resident = (long)cus * env_waves;

@@ -82,6 +82,54 @@ def noise_backward(grad_y, hop: int, n_filters: int, uniform=None, seed: int = 0
     return grad_h
 
 
+def calibrate_noise_residency(step=None, levels=(3, 4, 5, 6, 7, 8), settle_ms: float = 70.0, measure_ms: float = 40.0):
+    """Measures on THIS GPU how many wavefronts per CU the hop-128 noise kernel can take before its power density makes the chip drop
+    its shader clock (include/ddsp_hip.h: ddsp_noise_set_residency), and sets the fastest.
+
+    `step`: zero-argument callable that issues the caller's real workload on the current stream (default: the 16 kHz / 100 harmonics /
+    65 bands / batch 512 synthesis step on synthetic controls).  For each level, ascending (a level that trips the clock pollutes the
+    ~25 ms after it): `settle_ms` of back-to-back steps untimed, then `measure_ms` timed.  -> {"chosen": n, "ms_per_step": {n: ms}}.
+    ~0.7 s with the defaults; results of the kernels do not depend on the setting."""
+    import time
+    L = _lib.lib()
+    if step is None:
+        from . import synthetic as syn
+        from .harmonic_oscillator import osc_forward
+        shape = syn.CFG4_PER_GPU
+        ctl = {k: torch.from_numpy(v).cuda() for k, v in syn.make_controls(shape, 1, "all_live").items()}
+        count = [0]
+
+        def step():
+            y = osc_forward(ctl["f0"], ctl["c"], ctl["a"], shape.hop, shape.sample_rate)[0]
+            noise_forward(ctl["H"], shape.hop, seed=1, offset=count[0] << 32, out=y, accumulate=True)
+            count[0] += 1
+
+    def run_for(ms):
+        n, t0 = 0, time.perf_counter()
+        while 1e3 * (time.perf_counter() - t0) < ms:
+            for _ in range(4):
+                step()
+                n += 1
+            torch.cuda.synchronize()
+        return n, time.perf_counter() - t0
+
+    before = L.ddsp_noise_get_residency()
+    timings = {}
+    try:
+        for level in sorted(levels):
+            _lib.check(L.ddsp_noise_set_residency(int(level)), "ddsp_noise_set_residency")
+            run_for(settle_ms)
+            n, el = run_for(measure_ms)
+            timings[int(level)] = 1e3 * el / n
+    except BaseException:
+        L.ddsp_noise_set_residency(before)
+        raise
+    best = min(timings.values())
+    chosen = min(k for k, v in timings.items() if v <= 1.004 * best)       # (the lowest level within 0.4 % of the best)
+    _lib.check(L.ddsp_noise_set_residency(chosen), "ddsp_noise_set_residency")
+    return {"chosen": chosen, "ms_per_step": timings}
+
+
 class _NoiseFunction(torch.autograd.Function):
     """Differentiable w.r.t. H; the noise draw is a constant of the graph (filtered_noise.py:44-48)."""
 

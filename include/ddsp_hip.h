@@ -151,6 +151,14 @@ int ddsp_osc_plan(int B, int T, int H, int hop, int sample_rate, int *out, int c
  * ticks between that wavefront's start and end.  ghz is a HOST pointer; 0.0 if the kernel did not run.  Not for launch paths. */
 int ddsp_osc_clock(const void *scratch, int B, int T, int H, int hop, int sample_rate, double *ghz, void *stream);
 
+/* Wavefronts per CU (1..8; 0 = the default, 4) of the hop-128 / 65-band noise kernel's persistent grid.  A production knob, not a
+ * test hook: at the eight that fit, the kernel's power density makes an MI355X drop its shader clock for the ~25 ms that follow,
+ * which costs the kernels around it more than the noise kernel gains; where the clock gives way differs from box to box (between
+ * 4 and 8).  The default is safe on every box measured; a caller may measure its own box (the Python package's
+ * calibrate_noise_residency) and set more.  Results are bit-identical whatever the value.  Process-global, read once per launch. */
+int ddsp_noise_set_residency(int waves_per_cu);
+int ddsp_noise_get_residency(void);
+
 /* Test / tuning hook (process-global, read once per launch): bit 0 forces the generic one-frame-per-workgroup noise kernels
  * (any hop) instead of the batched ones (hop % 8 == 0, tile fits LDS); bit 1 keeps the direct (time-domain) forms where the
  * in-LDS FFT form would run (hop 512 with 2(F-1) <= hop); bit 2 takes the FFT form for hop 256 too (correct, not faster);

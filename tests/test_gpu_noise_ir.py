@@ -168,3 +168,31 @@ def test_matrix_product_backward_through_the_module():
     y1, g1 = grad(0)
     assert np.max(np.abs(y1 - y0)) <= TOL * max(1.0, float(np.max(np.abs(y0))))
     assert np.max(np.abs(g1 - g0)) <= 1e-5 * max(1.0, float(np.max(np.abs(g0))))
+
+
+def test_noise_residency_knob_changes_nothing_but_the_grid():
+    """ddsp_noise_set_residency (wavefronts per CU of the hop-128 kernel's persistent grid): bit-identical audio at every value, range
+    checked, default 4; calibrate_noise_residency picks one of the offered levels and leaves it set."""
+    L = ddsp._lib.lib()
+    assert L.ddsp_noise_set_residency(0) == 0 and L.ddsp_noise_get_residency() == 4
+    assert L.ddsp_noise_set_residency(9) != 0 and L.ddsp_noise_set_residency(-1) != 0
+    rng = np.random.default_rng(8)
+    B, T = 70, 500                                           # 2 187 groups of 16 frames: more than eight per CU, so the knob applies
+    Hn = dev(syn.controller_range(rng.standard_normal((B, T, 65), dtype=np.float32)))
+    try:
+        outs = []
+        for level in (0, 1, 3, 8):
+            assert L.ddsp_noise_set_residency(level) == 0
+            outs.append(ddsp.noise_forward(Hn, 128, seed=2, offset=9))
+        for y in outs[1:]:
+            assert torch.equal(y, outs[0])
+        count = [0]
+
+        def step():
+            ddsp.noise_forward(Hn, 128, seed=2, offset=count[0])
+            count[0] += 1
+
+        r = ddsp.calibrate_noise_residency(step, levels=(2, 4, 6), settle_ms=3.0, measure_ms=3.0)
+        assert r["chosen"] in (2, 4, 6) and set(r["ms_per_step"]) == {2, 4, 6} and L.ddsp_noise_get_residency() == r["chosen"]
+    finally:
+        L.ddsp_noise_set_residency(0)
