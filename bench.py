@@ -615,7 +615,7 @@ def main():
     done += extra
     settle_ms = 1e3 * (time.perf_counter() - t_settle)
     elapsed, records, y = timed_pass(done)
-    timed_first_launch = done + args.warmup       # index (from 0) of the first timed launch of each kernel in this process
+    timed_first_launch = (cal_i[0] - (1 << 20)) + done + args.warmup   # index (from 0) of the first timed launch of each kernel in this process (calibration steps included)
     assert bool(torch.isfinite(y).all()), "non-finite audio"
     # the other kernels' averages: K more steps right after the timed region, an event pair around every launch
     ddsp._lib.profile_enable(8 * args.steps + 16)

@@ -8,9 +8,9 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --no-live-pmc > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
 # PMC passes: counters only with --kernel-trace (separate runs; FETCH_SIZE and WRITE_SIZE do not fit one pass)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-live-pmc > /dev/null 2> "$OUT/pmc_fetch.err"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-live-pmc > /dev/null 2> "$OUT/pmc_write.err"
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-live-pmc > /dev/null 2> "$OUT/pmc_sq.err"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-live-pmc --no-calibrate > /dev/null 2> "$OUT/pmc_fetch.err"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-live-pmc --no-calibrate > /dev/null 2> "$OUT/pmc_write.err"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-live-pmc --no-calibrate > /dev/null 2> "$OUT/pmc_sq.err"
 # (summarise first so that the plain run below finds a PMC file stamped with these very sources -> `roofline.traffic` in its line)
 python3 tools/summarise_profiles.py "$OUT" "$ROUND" > /dev/null 2>&1
 cp "$OUT/${ROUND}_pmc.json" profiles/ 2>/dev/null
