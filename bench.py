@@ -94,6 +94,24 @@ def settle_clock(step, first, budget_ms=SETTLE_MS):
     return n
 
 
+def kernel_breakdown(step, first, steps, names):
+    """Average launch time of each kernel in `names`: one pass of `steps` steps per kernel, HIP events around THAT kernel only.  (Events
+    around every launch of a step open enough idle gaps for the chip's power management to drop the clock: the kernels themselves then
+    run ~10 % slower for the next 25 ms -- seen in the rocprofv3 trace of this very script -- so neither the timed region nor these
+    passes carry more than one event pair per step.)"""
+    out = {}
+    for j, name in enumerate(names):
+        ddsp._lib.profile_enable(2 * steps + 16, only=[name])
+        for i in range(steps):
+            step(first + j * steps + i)
+        torch.cuda.synchronize()
+        ms = [m for n, m in ddsp._lib.profile_read() if n == name]
+        ddsp._lib.profile_enable(0)
+        if ms:
+            out[name] = float(np.mean(ms))
+    return out
+
+
 def time_config(shape, seed, steps, warmup, f0_kind="all_live", noise_seed=7):
     """One BASELINE.json configuration on this GPU: `steps` passes of OscillatorBank.forward + FilteredNoise accumulated
     (in-kernel draw), inputs resident.  -> dict (ms_per_step by the host clock around a synchronised region, per-kernel
@@ -116,22 +134,13 @@ def time_config(shape, seed, steps, warmup, f0_kind="all_live", noise_seed=7):
         y = step(settled + warmup + i)
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / steps
-    # per-kernel averages from `steps` MORE steps with an event pair around every launch (a pair costs the stream ~4 us, 12 % of
-    # a cfg2 step: kept out of the timed region above)
-    ddsp._lib.profile_enable(8 * steps + 16)
-    for i in range(steps):
-        y = step(settled + warmup + steps + i)
-    torch.cuda.synchronize()
-    rec = {}
-    for name, ms in ddsp._lib.profile_read():
-        rec.setdefault(name, []).append(ms)
-    ddsp._lib.profile_enable(0)
     assert bool(torch.isfinite(y).all()), "non-finite audio"
     clock = measure_clock(x, shape, step)
+    # per-kernel averages from more steps, outside the timed region (kernel_breakdown)
+    kern = kernel_breakdown(step, settled + warmup + steps, steps, KERNELS)
     plan = ddsp._lib.osc_plan(shape.batch, shape.frames, shape.n_harmonics, shape.hop, shape.sample_rate)
     del y, x, osc
     torch.cuda.empty_cache()
-    kern = {k: float(np.mean(v)) for k, v in rec.items()}
     hs = shape.batch * shape.samples * shape.n_harmonics
     return {"workload": f"batch {shape.batch}, {shape.sample_rate} Hz, {shape.n_harmonics} harmonics, hop {shape.hop}, "
                         f"{shape.frames} frames (4 s), {shape.n_noise_filters} noise bands, {f0_kind} f0, in-kernel noise draw",
@@ -617,13 +626,6 @@ def main():
     elapsed, records, y = timed_pass(done)
     timed_first_launch = (cal_i[0] - (1 << 20)) + done + args.warmup   # index (from 0) of the first timed launch of each kernel in this process (calibration steps included)
     assert bool(torch.isfinite(y).all()), "non-finite audio"
-    # the other kernels' averages: K more steps right after the timed region, an event pair around every launch
-    ddsp._lib.profile_enable(8 * args.steps + 16)
-    for i in range(args.steps):
-        y = step(done + args.warmup + args.steps + i)
-    torch.cuda.synchronize()
-    breakdown = ddsp._lib.profile_read()
-    ddsp._lib.profile_enable(0)
     own_elapsed = elapsed
     if dist is not None:
         tmax = torch.tensor([elapsed, idle_elapsed], device="cuda", dtype=torch.float64)
@@ -632,20 +634,17 @@ def main():
     idle_kernel = {}
     for name, ms in idle_records:
         idle_kernel.setdefault(name, []).append(ms)
-    per_kernel = {}
-    for name, ms in breakdown:
-        if name != "osc_frame_synth":
-            per_kernel.setdefault(name, []).append(ms)
-    for name, ms in records:                       # (the timed region's own: the synth kernel)
-        per_kernel.setdefault(name, []).append(ms)
-    kern_ms = {k: float(np.mean(per_kernel[k])) for k in KERNELS if k in per_kernel}
+    # the shader clock this box's synth kernel runs at, measured in the kernel right after the timed region (every VALU
+    # fraction below is quoted against the 2.4 GHz peak AND against the peak at this clock: boxes of the pool differ by 10 %)
+    clock = measure_clock(x, shape, step) if rank == 0 else None
+    # the synth kernel's average: the timed region's own events; the other kernels': K more steps each, after the clock probe
+    kern_ms = kernel_breakdown(step, done + args.warmup + args.steps, args.steps, [k for k in KERNELS if k != "osc_frame_synth"])
+    kern_ms["osc_frame_synth"] = float(np.mean([ms for name, ms in records if name == "osc_frame_synth"]))
+    kern_ms = {k: kern_ms[k] for k in KERNELS if k in kern_ms}
     # every rank's own clock and per-kernel averages, gathered so that the first multi-GPU run diagnoses itself: a slow rank
     # (clock, thermal, a noisy neighbour on its XCDs) shows up by index instead of hiding inside the MAX
     diag = gather_rows(dist, [1e3 * own_elapsed / args.steps] + [kern_ms.get(k, float("nan")) for k in KERNELS], world, rank)
     del y
-    # the shader clock this box's synth kernel runs at, measured in the kernel right after the timed region (every VALU
-    # fraction below is quoted against the 2.4 GHz peak AND against the peak at this clock: boxes of the pool differ by 10 %)
-    clock = measure_clock(x, shape, step) if rank == 0 else None
 
     if rank == 0:
         samples_per_step = world * shape.batch * shape.samples
@@ -745,7 +744,9 @@ def main():
                                                   "frac": launch_samples * noise_macs / (noise_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS,
                                                   "frac_at_clock": launch_samples * noise_macs / (noise_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS * at_clock if at_clock else None}}},
             "kernel_ms": kern_ms,
-            "kernel_ms_source": "osc_frame_synth: HIP events inside the timed region; the others: K more steps right after it",
+            "kernel_ms_source": "osc_frame_synth: HIP events inside the timed region; each other kernel: K more steps with events around that kernel "
+                                "only.  An event pair is not a barrier: a reading includes what was left of the preceding kernel (the noise kernel's "
+                                "tail in osc_frame_totals: +0.03 ms against the rocprofv3 trace, profiles/rNN_kernel_stats.csv)",
             "per_rank_ms": [float(v) for v in diag[:, 0]],
             "per_rank_kernel_ms": {k: [float(v) for v in diag[:, 1 + j]] for j, k in enumerate(KERNELS)},
             "slowest_rank": int(np.argmax(diag[:, 0])),
