@@ -554,7 +554,10 @@ namespace {
 int noise_forward_impl(const float *Hmag, const float *uniform, float *y, int B, int T, int F, int hop, uint64_t seed,
                        uint64_t offset, const uint64_t *offset_dev, int accumulate, void *workspace, size_t workspace_bytes,
                        void *stream);
-constexpr long kIrProductMinFrames = 256;   // fewer frames (the real-time callback's 4): the cosine operand alone is more work
+// where the whole-batch matrix product pays for its extra launches (cosine operand + product; measured crossovers at 195 bands,
+// hop 512: forward between 2 752 and 5 504 frames, backward below 688): the real-time callback's 4 frames and the reference's
+// own training batch (16 x 172 frames) keep the cosine sums in the forward
+constexpr long kIrProductMinFramesFwd = 4096, kIrProductMinFramesBwd = 512;
 }
 
 extern "C" int ddsp_noise_forward(const float *Hmag, const float *uniform, float *y, int B, int T, int F, int hop,
@@ -574,7 +577,7 @@ extern "C" size_t ddsp_noise_workspace_bytes(int B, int T, int F, int hop)
 {
     if (B <= 0 || T <= 0 || F < 2 || hop <= 0) return 0;
     const long frames = (long)B * T;
-    return (ir_product_shape(F, hop) && frames >= kIrProductMinFrames) ? ir_workspace_bytes(frames, F) : 0;
+    return (ir_product_shape(F, hop) && frames >= kIrProductMinFramesBwd) ? ir_workspace_bytes(frames, F) : 0;
 }
 
 extern "C" int ddsp_noise_forward_ws(const float *Hmag, const float *uniform, float *y, int B, int T, int F, int hop, uint64_t seed,
@@ -602,7 +605,7 @@ int noise_forward_impl(const float *Hmag, const float *uniform, float *y, int B,
     const int mode = g_force_generic.load(std::memory_order_relaxed);
     // 195 bands at hop 512 (the reference's default shape) with a workspace: the impulse responses of the whole batch as one
     // matrix product (ddsp_noise_ir.hip), which the FFT form below then reads instead of summing cosines; mode bit 4 (tests, A/B) keeps the sums
-    if (workspace && !(mode & (3 | 16)) && ir_product_shape(F, hop) && (long)B * T >= kIrProductMinFrames &&
+    if (workspace && !(mode & (3 | 16)) && ir_product_shape(F, hop) && (long)B * T >= kIrProductMinFramesFwd &&
         workspace_bytes >= ir_workspace_bytes((long)B * T, F) && ((uintptr_t)workspace % 16) == 0) {
         hipError_t ie = hipSuccess;
         p.zrows = launch_noise_ir(Hmag, (long)B * T, F, workspace, s, &ie);
@@ -724,7 +727,7 @@ static int noise_backward_impl(const float *grad_y, const float *uniform, float 
         hipError_t fe = hipSuccess;
         // (a workspace is used only by the shapes of ddsp_noise_workspace_bytes; mode bit 4 keeps the direct kernels there)
         const bool ws_ok = workspace && !(g_force_generic.load(std::memory_order_relaxed) & 16) && ir_product_shape(F, hop) &&
-                           (long)B * T >= kIrProductMinFrames && workspace_bytes >= ir_workspace_bytes((long)B * T, F) &&
+                           (long)B * T >= kIrProductMinFramesBwd && workspace_bytes >= ir_workspace_bytes((long)B * T, F) &&
                            ((uintptr_t)workspace % 16) == 0;
         if (launch_noise_fft_backward(grad_y, uniform, grad_H, B, T, F, hop, seed, offset, offset_dev, ws_ok ? workspace : nullptr, s, &fe))
             return (int)fe;

@@ -96,9 +96,10 @@ int ddsp_noise_forward_counter(const float *Hmag, float *y, int B, int T, int F,
                                const uint64_t *counter_dev, int accumulate, void *stream);
 /* The same launch with a caller-provided workspace (device memory, 16-byte aligned, contents undefined before and after).
  * ddsp_noise_workspace_bytes is 0 for the shapes that have no use for one; for the reference's default shape (195 bands at
- * hop 512, config/default.py:15,19: 2(F-1) = 388 has no radix-2 transform) at >= 256 frames it holds the cosine operand and the
+ * hop 512, config/default.py:15,19: 2(F-1) = 388 has no radix-2 transform) at >= 512 frames it holds the cosine operand and the
  * impulse responses of the whole batch, which are then ONE split-bf16 matrix-core product (csrc/ddsp_noise_ir.hip) instead of
- * F x S/4 cosine sums per frame pair: 2x faster end to end.  A NULL / too small workspace takes the ddsp_noise_forward path
+ * F x S/4 cosine sums per frame pair: 2x faster end to end at large batches (the forward takes it from 4 096 frames on, the
+ * backward from 512: below, the extra launches cost more than the sums).  A NULL / too small workspace takes the ddsp_noise_forward path
  * (same results within rounding).  uniform and counter_dev exclude each other (both NULL: the draw starts at `offset`). */
 size_t ddsp_noise_workspace_bytes(int B, int T, int F, int hop);
 int ddsp_noise_forward_ws(const float *Hmag, const float *uniform, float *y, int B, int T, int F, int hop, uint64_t seed,

@@ -65,10 +65,10 @@ def sweep(cases: int, seed: int, verbose: bool = True):
         if rng.random() < 0.3:                                      # the benchmarked kernel forms: wavefront-private / in-LDS FFT
             nhop, F = [(128, 65), (128, 65), (512, 257), (512, 195)][int(rng.integers(4))]
             Tn = int(rng.integers(1, 70))                           # whole groups of 16 frames + a ragged remainder
-            if F in (195,) or (nhop == 512 and rng.random() < 0.3):     # >= 256 frames: the whole-batch matrix-product form (193..224 bands)
-                if rng.random() < 0.6:
+            if F in (195,) or (nhop == 512 and rng.random() < 0.3):     # >= 4 096 frames: the whole-batch matrix-product form (193..224 bands)
+                if rng.random() < 0.15:
                     F = int(rng.integers(193, 225)) if rng.random() < 0.5 else 195
-                    Tn = int(rng.integers(256 // B + 1, 256 // B + 40))
+                    Tn = int(rng.integers(4096 // B + 1, 4096 // B + 12))
         Hn = syn.controller_range(rng.standard_normal((B, Tn, F), dtype=np.float32))
         level = np.ones((B, Tn, 1), dtype=np.float32)
         if rng.random() < 0.3:                                      # frames of very different level, exactly-zero bands

@@ -30,9 +30,10 @@ def cosine_sums(fn):
         L.ddsp_noise_set_generic(0)
 
 
-@pytest.mark.parametrize("B,T,nf", [(3, 101, 195), (1, 256, 195), (5, 64, 200), (2, 150, 224), (4, 67, 193)])
+@pytest.mark.parametrize("B,T,nf", [(3, 1399, 195), (1, 4096, 195), (5, 821, 200), (2, 2051, 224), (4, 1027, 193)])
 def test_matrix_product_form_vs_oracle_and_cosine_sums(B, T, nf):
-    """Frame counts that end inside a 64-frame tile, a 16-frame operand and a frame pair; every band count the product is built for."""
+    """>= 4 096 frames (where the forward takes the product), ending inside a 64-frame tile, a 16-frame operand and a frame pair; band
+    counts across the range the product is built for."""
     rng = np.random.default_rng(B * 1000 + T + nf)
     Hn = syn.controller_range(rng.standard_normal((B, T, nf), dtype=np.float32))
     assert ddsp._lib.lib().ddsp_noise_workspace_bytes(B, T, nf, 512) > 0
@@ -48,7 +49,7 @@ def test_matrix_product_form_vs_oracle_and_cosine_sums(B, T, nf):
 
 def test_matrix_product_form_device_draw_and_accumulate():
     rng = np.random.default_rng(77)
-    B, T, nf = 2, 140, 195
+    B, T, nf = 2, 2100, 195
     Hn = syn.controller_range(rng.standard_normal((B, T, nf), dtype=np.float32))
     seed, offset = 4321, (3 << 32) + 5
     ref = oracle.noise_forward(Hn, None, 512, seed=seed, offset=offset)
@@ -66,7 +67,7 @@ def test_matrix_product_form_silent_and_unequal_frames():
     """An all-zero frame comes out as exact zeros (its pair partner's rounding does not leak in); a frame 1e6 times quieter than its
     partner keeps its RELATIVE accuracy (power-of-two equalisers from the product kernel's max |H| column)."""
     rng = np.random.default_rng(5)
-    B, T, nf = 1, 260, 195
+    B, T, nf = 1, 4100, 195
     Hn = syn.controller_range(rng.standard_normal((B, T, nf), dtype=np.float32))
     Hn[0, 10] = 0.0
     Hn[0, 21] *= 1e-6
@@ -81,24 +82,25 @@ def test_matrix_product_form_silent_and_unequal_frames():
 def test_workspace_contract():
     """ddsp_noise_workspace_bytes is 0 where no form uses one; ddsp_noise_forward_ws without a workspace is ddsp_noise_forward."""
     L = ddsp._lib.lib()
-    for B, T, nf, hop in ((512, 375, 257, 512), (512, 500, 65, 128), (1, 100, 195, 512), (1, 4, 195, 512), (8, 64, 195, 256), (0, 5, 195, 512)):
+    for B, T, nf, hop in ((512, 375, 257, 512), (512, 500, 65, 128), (1, 500, 195, 512), (1, 4, 195, 512), (8, 64, 195, 256), (0, 5, 195, 512)):
         assert L.ddsp_noise_workspace_bytes(B, T, nf, hop) == 0
-    need = L.ddsp_noise_workspace_bytes(2, 200, 195, 512)
-    assert need >= 400 * 196 * 4
+    need = L.ddsp_noise_workspace_bytes(2, 2100, 195, 512)
+    assert need >= 4200 * 196 * 4
+    assert L.ddsp_noise_workspace_bytes(2, 300, 195, 512) > 0       # (600 frames: the backward's threshold; the forward ignores it there)
     rng = np.random.default_rng(9)
-    Hn = dev(syn.controller_range(rng.standard_normal((2, 200, 195), dtype=np.float32)))
-    y0 = torch.empty(2, 200 * 512, device="cuda")
+    Hn = dev(syn.controller_range(rng.standard_normal((2, 2100, 195), dtype=np.float32)))
+    y0 = torch.empty(2, 2100 * 512, device="cuda")
     y1 = torch.empty_like(y0)
     s = torch.cuda.current_stream().cuda_stream
-    assert L.ddsp_noise_forward(Hn.data_ptr(), None, y0.data_ptr(), 2, 200, 195, 512, 11, 0, 0, s) == 0
-    assert L.ddsp_noise_forward_ws(Hn.data_ptr(), None, y1.data_ptr(), 2, 200, 195, 512, 11, 0, None, 0, None, 0, s) == 0
+    assert L.ddsp_noise_forward(Hn.data_ptr(), None, y0.data_ptr(), 2, 2100, 195, 512, 11, 0, 0, s) == 0
+    assert L.ddsp_noise_forward_ws(Hn.data_ptr(), None, y1.data_ptr(), 2, 2100, 195, 512, 11, 0, None, 0, None, 0, s) == 0
     assert torch.equal(y0, y1)
     small = torch.empty(need - 16, dtype=torch.uint8, device="cuda")      # too small: the same fallback, no overrun
-    assert L.ddsp_noise_forward_ws(Hn.data_ptr(), None, y1.data_ptr(), 2, 200, 195, 512, 11, 0, None, 0, small.data_ptr(),
+    assert L.ddsp_noise_forward_ws(Hn.data_ptr(), None, y1.data_ptr(), 2, 2100, 195, 512, 11, 0, None, 0, small.data_ptr(),
                                    ctypes.c_size_t(need - 16), s) == 0
     assert torch.equal(y0, y1)
     ws = torch.empty(need, dtype=torch.uint8, device="cuda")
-    assert L.ddsp_noise_forward_ws(Hn.data_ptr(), None, y1.data_ptr(), 2, 200, 195, 512, 11, 0, None, 0, ws.data_ptr(),
+    assert L.ddsp_noise_forward_ws(Hn.data_ptr(), None, y1.data_ptr(), 2, 2100, 195, 512, 11, 0, None, 0, ws.data_ptr(),
                                    ctypes.c_size_t(need), s) == 0
     assert float((y0 - y1).abs().max()) <= TOL * max(1.0, float(y0.abs().max()))
 
@@ -106,7 +108,7 @@ def test_workspace_contract():
 def test_matrix_product_form_in_a_captured_graph():
     """The three launches (cosine operand, product, FFT form) and torch's workspace allocation replay as one hipGraph."""
     rng = np.random.default_rng(31)
-    Hn = dev(syn.controller_range(rng.standard_normal((2, 130, 195), dtype=np.float32)))
+    Hn = dev(syn.controller_range(rng.standard_normal((2, 2060, 195), dtype=np.float32)))
     counter = torch.zeros(1, dtype=torch.int64, device="cuda")
     eager = ddsp.noise_forward(Hn, 512, seed=3, counter=counter).clone()
     side = torch.cuda.Stream()
@@ -122,7 +124,7 @@ def test_matrix_product_form_in_a_captured_graph():
     assert torch.equal(y, eager)
 
 
-@pytest.mark.parametrize("B,T,nf", [(3, 101, 195), (1, 257, 195), (2, 150, 224)])
+@pytest.mark.parametrize("B,T,nf", [(3, 171, 195), (1, 513, 195), (2, 300, 224)])
 def test_matrix_product_backward_vs_reference_autograd_and_direct_kernels(B, T, nf):
     """dH through the FFT-form correlation + transposed product against (a) torch autograd of the reference's op sequence on the CPU
     (oracle/torch_restatement.py: filtered_noise.py:7-53) and (b) the direct backward kernels it replaces.  1e-5 relative, as G17."""
@@ -147,7 +149,7 @@ def test_matrix_product_backward_vs_reference_autograd_and_direct_kernels(B, T, 
 def test_matrix_product_backward_through_the_module():
     """FilteredNoise autograd at the default shape: in-kernel draw, the backward regenerates it from the same counter."""
     rng = np.random.default_rng(3)
-    Hn = syn.controller_range(rng.standard_normal((2, 140, 195), dtype=np.float32))
+    Hn = syn.controller_range(rng.standard_normal((2, 2100, 195), dtype=np.float32))
 
     class Conf:
         n_harmonics, sample_rate, hop_length = 1, 44100, 512
